@@ -1,0 +1,151 @@
+/*
+ * npp_amd.h -- C ABI of the MI355X batched N++ environment stepper.
+ *
+ * The reference (Tetramputechture/nclone) is pure Python and has no FFI seam; the seam it
+ * does have is the object protocol of NPlayHeadless (nclone/nplay_headless.py:28) under the
+ * Gymnasium surface of NppEnvironment (nclone/gym_environment/base_environment.py:483 step,
+ * npp_environment.py:504 reset).  Each entry point below names the reference interface it
+ * replaces for N environments at once.  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (0 = NPP_OK);
+ *     npp_last_error(h) returns a human-readable message for the last failure on h
+ *     (h may be NULL for errors raised by npp_create).
+ *   - "d_" parameters are DEVICE-ACCESSIBLE pointers (hipMalloc'ed or hipHostMalloc'ed pinned
+ *     host memory); everything else is ordinary host memory.
+ *   - calls are asynchronous and ordered on the handle's HIP stream; npp_sync blocks.
+ *   - one host thread per handle.  One handle per GPU (one process per GPU for multi-GPU).
+ *   - all arithmetic of the physics path is IEEE fp64 without fused contraction, as in the
+ *     reference (CPython floats).
+ */
+#ifndef NPP_AMD_H
+#define NPP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct npp_handle_s *npp_handle;
+
+enum {
+    NPP_OK = 0,
+    NPP_ERR_INVALID = 1,     /* bad argument */
+    NPP_ERR_HIP = 2,         /* HIP runtime failure (message has the hipError string) */
+    NPP_ERR_UNSUPPORTED = 3, /* level uses entity types outside the accelerated path */
+    NPP_ERR_STATE = 4        /* call order (e.g. step before levels were loaded) */
+};
+
+/* npp_create flags */
+enum {
+    NPP_FLAG_AUTORESET = 1u << 0,         /* reset an env in-kernel when it terminates/truncates
+                                             (vector-env semantics; obs returned is the reset obs) */
+    NPP_FLAG_ALLOW_UNSUPPORTED = 1u << 1  /* load levels with unsupported entity types, ignoring
+                                             those entities (they are skipped, never simulated) */
+};
+
+/* out_flags bits written by npp_step */
+enum {
+    NPP_F_WON = 1u << 0,        /* ninja.has_won()  (ninja.py:1396)  */
+    NPP_F_DEAD = 1u << 1,       /* ninja.has_died() (ninja.py:1399)  */
+    NPP_F_SWITCH = 1u << 2,     /* exit_switch_activated() (nplay_headless.py:566) */
+    NPP_F_TRUNCATED = 1u << 3,  /* sim.frame >= limit (truncation_checker.py:46-77) */
+    NPP_F_CAUSE_MINE = 1u << 4, /* ninja.death_cause == "mine" */
+    NPP_F_CAUSE_IMPACT = 1u << 5/* ninja.death_cause == "terminal_impact" */
+};
+
+#define NPP_GAME_STATE_DIM 41   /* gym_environment/constants.py:25 */
+#define NPP_ACTION_DIM 6        /* base_environment.py:150 Discrete(6) */
+#define NPP_ENTITY_POS_DIM 6    /* observation_processor.py:340-361 */
+#define NPP_FRAME_W 84          /* gym_environment/constants.py:12-13 */
+#define NPP_FRAME_H 84
+#define NPP_DUMP_F64 12
+#define NPP_DUMP_I32 32
+
+/* Output block of npp_step.  Any pointer may be NULL (that output is skipped). */
+typedef struct {
+    float *d_game_state;      /* [N,41] f32: get_ninja_state() (nplay_headless.py:735-924) + time_remaining
+                                 (base_environment.py:2811-2829), cast like observation_processor.py:284-302 */
+    int8_t *d_action_mask;    /* [N,6]  i8 : ninja.get_valid_action_mask() (ninja.py:628-839) */
+    float *d_entity_pos;      /* [N,6]  f32: [ninja, exit switch, exit door] / (1056, 600) */
+    uint8_t *d_flags;         /* [N]    u8 : NPP_F_* of the state the step ended in (before auto-reset) */
+    float *d_reward;          /* [N]    f32: sparse terminal reward only */
+    uint16_t *d_frames;       /* [N]    u16: ticks executed this step (info["frame_skip_stats"]) */
+    float *d_terminal_state;  /* [N,41] f32: game_state of the terminal state for envs that were
+                                 auto-reset this step (rows of other envs are left untouched) */
+} npp_step_out;
+
+/* Simulator()+NPlayHeadless() for n_envs environments on GPU device_id. */
+int npp_create(int n_envs, int device_id, unsigned flags, npp_handle *out);
+int npp_destroy(npp_handle h);
+const char *npp_last_error(npp_handle h);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all launches of h. NULL = default stream. */
+int npp_set_stream(npp_handle h, void *hip_stream);
+int npp_sync(npp_handle h);
+
+/* NPlayHeadless.load_map_from_map_data (nplay_headless.py:195) -> Simulator.load (nsim.py:51) for a SET of
+ * levels.  blob holds the raw map_data values of all levels back to back as doubles (generated levels carry
+ * fractional entity coordinates); level i is blob[offsets[i] .. offsets[i+1]).
+ * The host compiles every level (tiles -> ordered per-cell segment lists, entities -> per-cell tables) and
+ * uploads the tables.  Replaces any previously loaded set and resets every env to level 0. */
+int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, int n_levels);
+
+/* Which level each env plays (EnvMapLoader.load_map choice, env_map_loader.py:111-208).  env_ids == NULL
+ * means envs 0..n-1.  The listed envs are reset (Simulator.reset, nsim.py:62). */
+int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level_ids, int n);
+
+/* Simulator.reset / fast_reset (nsim.py:62-140) for the envs whose mask byte is non-zero (NULL = all). */
+int npp_reset(npp_handle h, const uint8_t *env_mask);
+
+/* Truncation limit in frames (truncation_checker.py:21-29); limits == NULL sets `all` for every env. */
+int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all);
+
+/* NppEnvironment.step for all envs (base_environment.py:483-755): d_actions[N] in 0..5
+ * (_actions_to_execute, :366-402), up to frame_skip ticks with early stop on win/death (:535-609),
+ * truncation check (:613), observation (:627,680). */
+int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_step_out *out);
+
+/* NPlayHeadless.tick(h, j) (nplay_headless.py:322) for all envs, n_ticks times, driven by replay input
+ * bytes d_inputs[n_ticks][N] (bit0 jump, bit1 right, bit2 left: replay/replay_executor.py:61-84).
+ * No early stop, no truncation, no auto-reset: the caller polls state like tools/test_replay_playback.py. */
+int npp_tick(npp_handle h, const uint8_t *d_inputs, int n_ticks);
+
+/* Observation of the current state without stepping (NppEnvironment._get_observation, used by reset()). */
+int npp_observe(npp_handle h, const npp_step_out *out);
+
+/* player_frame (84x84 u8) around each ninja, rasterised on device (nsim_renderer.py:71-134 +
+ * observation_processor.py:207-282 crop incl. its axis swap).  d_out is [N,84,84]. */
+int npp_render_player_frame(npp_handle h, uint8_t *d_out);
+
+/* Parity hook: copies the simulator state of envs [env0, env0+count) to HOST buffers.
+ * f64 [count][NPP_DUMP_F64]: xpos ypos xspeed yspeed floor_nx floor_ny ceil_nx ceil_ny xspeed_old yspeed_old
+ *                            applied_gravity applied_drag
+ * i32 [count][NPP_DUMP_I32]: see DESIGN.md ("state dump layout"). */
+int npp_dump_state(npp_handle h, int env0, int count, double *f64_out, int32_t *i32_out);
+
+/* Parity hook: per-entity dynamic state of one env in level (map) order:
+ * mines -> state 0/1/2, exit door -> switch_hit, others -> active.  Returns count via *n_out. */
+int npp_dump_entities(npp_handle h, int env, int32_t *out, int max, int *n_out);
+
+/* Parity hook: the compiled collision table of a level as rows of 8 int16
+ * (cell x, cell y, kind, then x1,y1,x2,y2,oriented | cx,cy,hor,ver,convex), in query order. */
+int npp_dump_level_segments(npp_handle h, int level, int16_t *out, int max_rows, int *n_out);
+
+/* Host-only utilities (no GPU, no handle): run the level compiler on one level.  Used by the CPU test-suite to
+ * check the compiler against the reference's ordered segment dump and entity tables.
+ * segments: rows of 8 int16 as in npp_dump_level_segments.  entities: rows of 6 doubles in map order:
+ * kind (1 mine, 2 gold, 3 exit door, 4 exit switch, 6 locked-door switch), x, y, cell x, cell y, initial 2-bit state. */
+int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int max_rows, int *n_out,
+                               uint32_t *unsupported_mask);
+int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out);
+
+int npp_num_envs(npp_handle h);
+int npp_num_levels(npp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPP_AMD_H */

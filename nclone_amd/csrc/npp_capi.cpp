@@ -1,0 +1,430 @@
+// npp_capi.cpp -- the C ABI declared in include/npp_amd.h: handle management, level upload, launches.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/npp_amd.h"
+#include "npp_internal.hpp"
+#include "npp_level.hpp"
+
+using namespace npp;
+
+struct npp_handle_s {
+    int n = 0;
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t stream = nullptr;
+    double *d_f64 = nullptr;
+    uint32_t *d_u32 = nullptr;
+    uint32_t *d_ent = nullptr;
+    int32_t *d_env_level = nullptr;
+    int32_t *d_trunc = nullptr;
+    uint8_t *d_mask = nullptr;
+    unsigned char *d_blob = nullptr;
+    LevelHdr *d_hdr = nullptr;
+    int n_words_max = 1;
+    uint32_t lds_hot_cap = 0;
+    std::vector<CompiledLevel> levels;
+    std::vector<LevelHdr> hdrs;
+    std::vector<int32_t> env_level;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+namespace {
+
+constexpr uint32_t LDS_BUDGET = 64 * 1024;  // per workgroup (160 KiB per CU: at least two workgroups per CU)
+
+int fail(npp_handle h, int code, const std::string &msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return fail(h, NPP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+KernelArgs base_args(npp_handle h) {
+    KernelArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.f64 = h->d_f64;
+    a.u32 = h->d_u32;
+    a.ent_bits = h->d_ent;
+    a.env_level = h->d_env_level;
+    a.trunc_limit = h->d_trunc;
+    a.hdr = h->d_hdr;
+    a.blob = h->d_blob;
+    a.n = h->n;
+    a.autoreset = (h->flags & NPP_FLAG_AUTORESET) ? 1 : 0;
+    a.n_words_max = h->n_words_max;
+    a.lds_hot_cap = h->lds_hot_cap;
+    return a;
+}
+
+void fill_out(KernelArgs &a, const npp_step_out *o) {
+    if (!o) return;
+    a.out.game_state = o->d_game_state;
+    a.out.action_mask = o->d_action_mask;
+    a.out.entity_pos = o->d_entity_pos;
+    a.out.flags = o->d_flags;
+    a.out.reward = o->d_reward;
+    a.out.frames = o->d_frames;
+    a.out.terminal_state = o->d_terminal_state;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *npp_last_error(npp_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int npp_create(int n_envs, int device_id, unsigned flags, npp_handle *out) {
+    if (!out || n_envs <= 0) return fail(nullptr, NPP_ERR_INVALID, "npp_create: n_envs must be > 0 and out non-NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, NPP_ERR_HIP, "npp_create: no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= count) return fail(nullptr, NPP_ERR_INVALID, "npp_create: bad device_id");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    npp_handle h = new npp_handle_s();
+    h->n = n_envs;
+    h->device = device_id;
+    h->flags = flags;
+    size_t N = (size_t)n_envs;
+    hipError_t e1 = hipMalloc((void **)&h->d_f64, sizeof(double) * NF64 * N);
+    hipError_t e2 = hipMalloc((void **)&h->d_u32, sizeof(uint32_t) * NU32 * N);
+    hipError_t e3 = hipMalloc((void **)&h->d_env_level, sizeof(int32_t) * N);
+    hipError_t e4 = hipMalloc((void **)&h->d_trunc, sizeof(int32_t) * N);
+    hipError_t e5 = hipMalloc((void **)&h->d_mask, N);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+        npp_destroy(h);
+        return fail(nullptr, NPP_ERR_HIP, "npp_create: hipMalloc failed");
+    }
+    h->env_level.assign(N, 0);
+    std::vector<int32_t> lim(N, 10000);  // MAX_TIME_IN_FRAMES fallback (gym_environment/constants.py:8)
+    hipMemcpy(h->d_trunc, lim.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice);
+    hipMemset(h->d_env_level, 0, sizeof(int32_t) * N);
+    *out = h;
+    return NPP_OK;
+}
+
+int npp_destroy(npp_handle h) {
+    if (!h) return NPP_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
+    hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr);
+    delete h;
+    return NPP_OK;
+}
+
+int npp_set_stream(npp_handle h, void *hip_stream) {
+    if (!h) return NPP_ERR_INVALID;
+    h->stream = (hipStream_t)hip_stream;
+    return NPP_OK;
+}
+
+int npp_sync(npp_handle h) {
+    if (!h) return NPP_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NPP_OK;
+}
+
+int npp_num_envs(npp_handle h) { return h ? h->n : 0; }
+int npp_num_levels(npp_handle h) { return h ? (int)h->levels.size() : 0; }
+
+int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, int n_levels) {
+    if (!h || !blob || !offsets || n_levels <= 0) return fail(h, NPP_ERR_INVALID, "npp_load_levels: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<CompiledLevel> lv(n_levels);
+    for (int i = 0; i < n_levels; i++) {
+        std::string err;
+        if (offsets[i + 1] < offsets[i] || !compile_level(blob + offsets[i], offsets[i + 1] - offsets[i], lv[i], err))
+            return fail(h, NPP_ERR_INVALID, "npp_load_levels: level " + std::to_string(i) + ": " + err);
+        if (lv[i].unsupported_mask && !(h->flags & NPP_FLAG_ALLOW_UNSUPPORTED)) {
+            std::string t;
+            for (int b = 0; b < 32; b++)
+                if (lv[i].unsupported_mask & (1u << b)) t += (t.empty() ? "" : ",") + std::to_string(b);
+            return fail(h, NPP_ERR_UNSUPPORTED, "npp_load_levels: level " + std::to_string(i) +
+                                                    " uses entity types outside the accelerated path: " + t);
+        }
+    }
+    // ---- pack the blob
+    std::vector<unsigned char> host;
+    std::vector<LevelHdr> hdrs(n_levels);
+    int words_max = 1;
+    uint32_t hot_max = 0;
+    auto append = [&](const void *p, size_t bytes, uint32_t align) -> uint32_t {
+        uint32_t off = align_up((uint32_t)host.size(), align);
+        host.resize(off + bytes);
+        if (bytes) std::memcpy(host.data() + off, p, bytes);
+        return off;
+    };
+    for (int i = 0; i < n_levels; i++) {
+        const CompiledLevel &L = lv[i];
+        LevelHdr &H = hdrs[i];
+        std::memset(&H, 0, sizeof(H));
+        uint32_t hot_bytes = align_up(HOT_SEGS + 2u * (uint32_t)L.segs.size(), 16);
+        std::vector<unsigned char> hot(hot_bytes, 0);
+        std::memcpy(hot.data() + HOT_SEG_START, L.seg_start.data(), 2 * L.seg_start.size());
+        std::memcpy(hot.data() + HOT_ENT_START, L.ent_start.data(), 2 * L.ent_start.size());
+        std::memcpy(hot.data() + HOT_BOUNDS, L.cell_bounds.data(), L.cell_bounds.size());
+        if (!L.segs.empty()) std::memcpy(hot.data() + HOT_SEGS, L.segs.data(), 2 * L.segs.size());
+        H.off_hot = append(hot.data(), hot.size(), 16);
+        H.hot_bytes = hot_bytes;
+        H.off_ent_x = append(L.ent_x.data(), 8 * L.ent_x.size(), 8);
+        H.off_ent_y = append(L.ent_y.data(), 8 * L.ent_y.size(), 8);
+        H.off_ent_meta = append(L.ent_meta.data(), 4 * L.ent_meta.size(), 4);
+        H.off_init_words = append(L.ent_init_words.data(), 4 * L.ent_init_words.size(), 4);
+        H.off_tiles = append(L.tiles.data(), L.tiles.size(), 4);
+        H.n_seg = (uint32_t)L.segs.size();
+        H.n_ent = (uint32_t)L.ent_x.size();
+        H.n_words = (uint32_t)L.ent_init_words.size();
+        H.n_think = (uint32_t)L.n_thinkable;
+        H.obs_switch = L.obs_switch;
+        H.obs_door = L.obs_door;
+        H.spawn_x = L.spawn_x; H.spawn_y = L.spawn_y;
+        if (L.obs_switch >= 0) {   // exit_switch_position / exit_door_position (nplay_headless.py:578-616)
+            H.sw_x = L.ent_x[L.obs_switch]; H.sw_y = L.ent_y[L.obs_switch];
+            H.door_x = L.ent_x[L.obs_door]; H.door_y = L.ent_y[L.obs_door];
+        }
+        words_max = std::max(words_max, (int)H.n_words);
+        H.fits_lds = 1;
+        hot_max = std::max(hot_max, hot_bytes);
+    }
+    // LDS plan: staged level + entity words + observation staging must fit the per-workgroup budget
+    uint32_t fixed = (uint32_t)words_max * BLOCK * 4 + BLOCK * 41 * 4;
+    uint32_t hot_cap = hot_max;
+    if (fixed + hot_cap > LDS_BUDGET) {
+        hot_cap = fixed < LDS_BUDGET ? ((LDS_BUDGET - fixed) / 16) * 16 : 0;
+        for (auto &H : hdrs) H.fits_lds = H.hot_bytes <= hot_cap ? 1 : 0;
+    }
+    if (fixed + hot_cap > 160 * 1024) return fail(h, NPP_ERR_INVALID, "npp_load_levels: entity tables exceed LDS");
+    // ---- upload (replaces the previous set)
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(h->d_blob); h->d_blob = nullptr;
+    hipFree(h->d_hdr); h->d_hdr = nullptr;
+    hipFree(h->d_ent); h->d_ent = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&h->d_blob, host.size() + 16));
+    HIP_TRY(h, hipMemcpy(h->d_blob, host.data(), host.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc((void **)&h->d_hdr, sizeof(LevelHdr) * n_levels));
+    HIP_TRY(h, hipMemcpy(h->d_hdr, hdrs.data(), sizeof(LevelHdr) * n_levels, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc((void **)&h->d_ent, sizeof(uint32_t) * (size_t)words_max * h->n));
+    HIP_TRY(h, hipMemset(h->d_ent, 0, sizeof(uint32_t) * (size_t)words_max * h->n));
+    h->levels.swap(lv);
+    h->hdrs.swap(hdrs);
+    h->n_words_max = words_max;
+    h->lds_hot_cap = hot_cap;
+    std::fill(h->env_level.begin(), h->env_level.end(), 0);
+    HIP_TRY(h, hipMemset(h->d_env_level, 0, sizeof(int32_t) * (size_t)h->n));
+    return npp_reset(h, nullptr);
+}
+
+int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level_ids, int n) {
+    if (!h || !level_ids || n <= 0) return fail(h, NPP_ERR_INVALID, "npp_assign_levels: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_assign_levels: no levels loaded");
+    if (!env_ids && n != h->n) return fail(h, NPP_ERR_INVALID, "npp_assign_levels: env_ids == NULL needs n == n_envs");
+    std::vector<uint8_t> mask(h->n, 0);
+    for (int i = 0; i < n; i++) {
+        int e = env_ids ? env_ids[i] : i;
+        if (e < 0 || e >= h->n || level_ids[i] < 0 || level_ids[i] >= (int)h->levels.size())
+            return fail(h, NPP_ERR_INVALID, "npp_assign_levels: index out of range");
+        h->env_level[e] = level_ids[i];
+        mask[e] = 1;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_env_level, h->env_level.data(), sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
+    return npp_reset(h, mask.data());
+}
+
+int npp_reset(npp_handle h, const uint8_t *env_mask) {
+    if (!h) return NPP_ERR_INVALID;
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reset: no levels loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    KernelArgs a = base_args(h);
+    if (env_mask) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        a.reset_mask = h->d_mask;
+    }
+    HIP_TRY(h, launch_reset(a, h->stream));
+    if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));  // env_mask is caller memory: finish the copy
+    return NPP_OK;
+}
+
+int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
+    if (!h) return NPP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<int32_t> lim;
+    if (!limits) { lim.assign(h->n, all); limits = lim.data(); }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_trunc, limits, sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
+    return NPP_OK;
+}
+
+int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_step_out *out) {
+    if (!h || !d_actions || frame_skip <= 0) return fail(h, NPP_ERR_INVALID, "npp_step: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_step: no levels loaded");
+    KernelArgs a = base_args(h);
+    a.inputs = d_actions;
+    a.n_ticks = frame_skip;
+    a.mode = 0;
+    fill_out(a, out);
+    HIP_TRY(h, launch_step(a, h->stream));
+    return NPP_OK;
+}
+
+int npp_tick(npp_handle h, const uint8_t *d_inputs, int n_ticks) {
+    if (!h || !d_inputs || n_ticks <= 0) return fail(h, NPP_ERR_INVALID, "npp_tick: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_tick: no levels loaded");
+    KernelArgs a = base_args(h);
+    a.inputs = d_inputs;
+    a.n_ticks = n_ticks;
+    a.mode = 1;
+    a.autoreset = 0;
+    HIP_TRY(h, launch_step(a, h->stream));
+    return NPP_OK;
+}
+
+int npp_observe(npp_handle h, const npp_step_out *out) {
+    if (!h || !out) return fail(h, NPP_ERR_INVALID, "npp_observe: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_observe: no levels loaded");
+    KernelArgs a = base_args(h);
+    a.n_ticks = 0;
+    a.mode = 0;
+    a.autoreset = 0;
+    fill_out(a, out);
+    HIP_TRY(h, launch_step(a, h->stream));
+    return NPP_OK;
+}
+
+int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
+    if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_player_frame: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_player_frame: no levels loaded");
+    KernelArgs a = base_args(h);
+    HIP_TRY(h, launch_render(a, d_out, h->stream));
+    return NPP_OK;
+}
+
+int npp_dump_state(npp_handle h, int env0, int count, double *f64_out, int32_t *i32_out) {
+    if (!h || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_dump_state: bad range");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_dump_state: no levels loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    size_t N = (size_t)h->n;
+    std::vector<double> f((size_t)NF64 * count);
+    std::vector<uint32_t> u((size_t)NU32 * count);
+    std::vector<uint32_t> w((size_t)h->n_words_max * count);
+    for (int k = 0; k < NF64; k++)
+        HIP_TRY(h, hipMemcpy(f.data() + (size_t)k * count, h->d_f64 + k * N + env0, sizeof(double) * count, hipMemcpyDeviceToHost));
+    for (int k = 0; k < NU32; k++)
+        HIP_TRY(h, hipMemcpy(u.data() + (size_t)k * count, h->d_u32 + k * N + env0, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+    for (int k = 0; k < h->n_words_max; k++)
+        HIP_TRY(h, hipMemcpy(w.data() + (size_t)k * count, h->d_ent + k * N + env0, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++) {
+        auto F = [&](int k) { return f[(size_t)k * count + i]; };
+        uint32_t A = u[(size_t)U_A * count + i], B = u[(size_t)U_B * count + i], C = u[(size_t)U_C * count + i],
+                 D = u[(size_t)U_D * count + i], E = u[(size_t)U_E * count + i];
+        int gjump = (A >> 13) & 1, dslow = (A >> 14) & 1;
+        if (f64_out) {
+            double *o = f64_out + (size_t)i * NPP_DUMP_F64;
+            o[0] = F(F_X); o[1] = F(F_Y); o[2] = F(F_VX); o[3] = F(F_VY);
+            o[4] = F(F_FNX); o[5] = F(F_FNY); o[6] = F(F_CNX); o[7] = F(F_CNY);
+            o[8] = F(F_VXO); o[9] = F(F_VYO);
+            o[10] = gjump ? 0.01111111111111111 : 0.06666666666666665;
+            o[11] = dslow ? 0.8617738760127536 : 0.9933221725495059;
+        }
+        if (i32_out) {
+            int32_t *o = i32_out + (size_t)i * NPP_DUMP_I32;
+            std::memset(o, 0, sizeof(int32_t) * NPP_DUMP_I32);
+            int lvl = h->env_level[env0 + i];
+            const CompiledLevel &L = h->levels[lvl];
+            int sw_active = 2;
+            if (L.obs_switch >= 0) sw_active = (w[(size_t)(L.obs_switch >> 4) * count + i] >> ((L.obs_switch & 15) * 2)) & 3;
+            o[0] = A & 15; o[1] = (A >> 4) & 1; o[2] = (A >> 6) & 1; o[3] = (A >> 7) & 3;
+            o[4] = (A >> 15) & 7; o[5] = (A >> 18) & 7; o[6] = (A >> 21) & 7; o[7] = (A >> 24) & 7;
+            o[8] = (B >> 6) & 255; o[9] = (B >> 14) & 255; o[10] = B & 63;
+            o[11] = !gjump; o[12] = !dslow; o[13] = sw_active;
+            o[14] = (D >> 16) & 255; o[15] = D >> 24; o[16] = C & 0xffff; o[17] = C >> 16;
+            o[18] = (A >> 5) & 1; o[19] = (A >> 9) & 1; o[20] = (A >> 27) & 3; o[21] = (A >> 29) & 1;
+            o[22] = D & 0xffff; o[23] = (int)((A >> 10) & 3) - 1; o[24] = (A >> 12) & 1; o[25] = (B >> 22) & 15;
+            o[26] = E & 0xffff; o[27] = lvl;
+        }
+    }
+    return NPP_OK;
+}
+
+int npp_dump_entities(npp_handle h, int env, int32_t *out, int max, int *n_out) {
+    if (!h || env < 0 || env >= h->n || !out || !n_out) return fail(h, NPP_ERR_INVALID, "npp_dump_entities: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_dump_entities: no levels loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const CompiledLevel &L = h->levels[h->env_level[env]];
+    std::vector<uint32_t> w(h->n_words_max);
+    for (int k = 0; k < h->n_words_max; k++)
+        HIP_TRY(h, hipMemcpy(&w[k], h->d_ent + (size_t)k * h->n + env, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int n = (int)L.ent_map_order.size();
+    if (n > max) n = max;
+    for (int i = 0; i < n; i++) {
+        int slot = L.ent_map_order[i];
+        out[i] = (w[slot >> 4] >> ((slot & 15) * 2)) & 3;
+    }
+    *n_out = n;
+    return NPP_OK;
+}
+
+int npp_dump_level_segments(npp_handle h, int level, int16_t *out, int max_rows, int *n_out) {
+    if (!h || level < 0 || level >= (int)h->levels.size() || !out || !n_out)
+        return fail(h, NPP_ERR_INVALID, "npp_dump_level_segments: bad arguments");
+    int r = dump_segments(h->levels[level], out, max_rows);
+    if (r < 0) return fail(h, NPP_ERR_INVALID, "npp_dump_level_segments: buffer too small");
+    *n_out = r;
+    return NPP_OK;
+}
+
+int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int max_rows, int *n_out, uint32_t *unsupported_mask) {
+    if (!map || !out || !n_out) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_segments: bad arguments");
+    CompiledLevel L;
+    std::string err;
+    if (!compile_level(map, n, L, err)) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_segments: " + err);
+    int r = dump_segments(L, out, max_rows);
+    if (r < 0) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_segments: buffer too small");
+    *n_out = r;
+    if (unsupported_mask) *unsupported_mask = L.unsupported_mask;
+    return NPP_OK;
+}
+
+int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out) {
+    if (!map || !out || !n_out) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_entities: bad arguments");
+    CompiledLevel L;
+    std::string err;
+    if (!compile_level(map, n, L, err)) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_entities: " + err);
+    int ne = (int)L.ent_map_order.size();
+    if (ne > max_rows) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_entities: buffer too small");
+    // cell of a slot from the CSR
+    std::vector<int> cell_of_slot(ne, 0);
+    for (int c = 0; c < N_CELLS; c++)
+        for (int s = L.ent_start[c]; s < L.ent_start[c + 1]; s++) cell_of_slot[s] = c;
+    for (int i = 0; i < ne; i++) {
+        int s = L.ent_map_order[i];
+        double *o = out + (size_t)i * 6;
+        o[0] = L.ent_meta[s] & 15u;
+        o[1] = L.ent_x[s];
+        o[2] = L.ent_y[s];
+        o[3] = cell_of_slot[s] / GRID_H;
+        o[4] = cell_of_slot[s] % GRID_H;
+        o[5] = (L.ent_meta[s] >> 4) & 3u;
+    }
+    *n_out = ne;
+    return NPP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// npp_internal.hpp -- structures shared between the C ABI (npp_capi.cpp) and the HIP kernels (npp_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace npp {
+
+// ---- SoA ninja state: f64 plane k of env e lives at d_f64[k * n_envs + e] (coalesced per wave) -------------------
+enum F64Plane { F_X = 0, F_Y, F_VX, F_VY, F_VXO, F_VYO, F_FNX, F_FNY, F_CNX, F_CNY, NF64 };
+// u32 planes, bit layout in npp_kernels.hip (pack_state / unpack_state)
+enum U32Plane { U_A = 0, U_B, U_C, U_D, U_E, NU32 };
+
+// Per-level header (device copy); offsets are bytes into the level blob.
+// The "hot" region [off_hot, off_hot + hot_bytes) = seg_start | ent_start | cell_bounds | segs is what a
+// workgroup stages into LDS when all of its envs play this level.
+struct LevelHdr {
+    uint32_t off_hot;
+    uint32_t hot_bytes;   // multiple of 16
+    uint32_t off_ent_x;   // f64[n_ent]
+    uint32_t off_ent_y;   // f64[n_ent]
+    uint32_t off_ent_meta;  // u32[n_ent]
+    uint32_t off_init_words;  // u32[n_words]
+    uint32_t off_tiles;   // u8[1100]
+    uint32_t n_seg;
+    uint32_t n_ent;
+    uint32_t n_words;
+    uint32_t n_think;
+    int32_t obs_switch;
+    int32_t obs_door;
+    uint32_t fits_lds;
+    double spawn_x, spawn_y;
+    double sw_x, sw_y, door_x, door_y;
+};
+
+// offsets inside the hot region (bytes)
+constexpr uint32_t HOT_SEG_START = 0;      // u16[1101] (2202 -> padded 2208)
+constexpr uint32_t HOT_ENT_START = 2208;   // u16[1101]
+constexpr uint32_t HOT_BOUNDS = 4416;      // u8[1100] (-> padded 1104)
+constexpr uint32_t HOT_SEGS = 5520;        // u16[n_seg]
+
+struct StepOut {
+    float *game_state;
+    int8_t *action_mask;
+    float *entity_pos;
+    uint8_t *flags;
+    float *reward;
+    uint16_t *frames;
+    float *terminal_state;
+};
+
+struct KernelArgs {
+    double *f64;          // [NF64][n]
+    uint32_t *u32;        // [NU32][n]
+    uint32_t *ent_bits;   // [n_words_max][n]
+    const int32_t *env_level;   // [n]
+    const int32_t *trunc_limit; // [n]
+    const LevelHdr *hdr;  // [n_levels]
+    const unsigned char *blob;
+    const uint8_t *inputs;  // actions [n] (mode 0) or replay bytes [n_ticks][n] (mode 1)
+    const uint8_t *reset_mask;  // reset kernel only; NULL = all
+    int n;
+    int n_ticks;          // frame_skip (mode 0) or tick count (mode 1); 0 = observe only
+    int mode;             // 0 gym step, 1 raw ticks
+    int autoreset;
+    int n_words_max;
+    uint32_t lds_hot_cap; // bytes reserved for a staged level
+    StepOut out;
+};
+
+constexpr int BLOCK = 64;  // one wavefront per workgroup: one lane per environment
+
+// dynamic LDS layout: [hot_cap][ent words: n_words_max * 64 * 4][obs staging: 64 * 41 * 4]
+inline size_t lds_bytes(uint32_t hot_cap, int n_words_max) {
+    return (size_t)hot_cap + (size_t)n_words_max * BLOCK * 4 + (size_t)BLOCK * 41 * 4;
+}
+
+hipError_t launch_step(const KernelArgs &a, hipStream_t s);
+hipError_t launch_reset(const KernelArgs &a, hipStream_t s);
+hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
+
+}  // namespace npp

@@ -1,0 +1,291 @@
+// npp_level.cpp -- see npp_level.hpp.  Host C++ only (no HIP).
+#include "npp_level.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace npp {
+namespace {
+
+// Orthogonal half-edge contributions of tile types 0..33 as two 12-bit masks (bit k = k-th entry of the
+// reference's per-tile list, nclone/tile_definitions.py:137-185: 6 horizontal half-edges left->right,
+// top->bottom, then 6 vertical ones top->bottom, left->right).  NEG = normal up/left (-1), POS = down/right (+1).
+const uint16_t ORTHO_NEG[34] = {0x000, 0x0c3, 0x043, 0x302, 0x08c, 0x0c1, 0x0c3, 0x003, 0x000, 0x0c0, 0x0c3, 0x003,
+                                0x000, 0x0c0, 0x0c3, 0x003, 0x000, 0x0c0, 0x043, 0x003, 0x000, 0x080, 0x0c3, 0x043,
+                                0x080, 0x0c0, 0x0c1, 0x002, 0x000, 0x0c0, 0x0c3, 0x003, 0x002, 0x0c1};
+const uint16_t ORTHO_POS[34] = {0x000, 0xc30, 0x40c, 0xc20, 0x830, 0x310, 0x000, 0xc00, 0xc30, 0x030, 0x000, 0xc00,
+                                0xc30, 0x030, 0x000, 0xc00, 0xc30, 0x030, 0x000, 0x400, 0x830, 0x030, 0x400, 0xc00,
+                                0xc30, 0x830, 0x000, 0xc00, 0xc20, 0x010, 0x010, 0xc20, 0xc30, 0x030};
+
+// Non-orthogonal piece of a tile, already in packed-segment units (12 px): 0 = none.
+// Diagonals (tile_definitions.py:189-210) and quarter circles (:214-223).
+uint16_t pack_linear(int x1, int y1, int x2, int y2) {
+    return (uint16_t)(0u | (x1 << 2) | (y1 << 4) | (x2 << 6) | (y2 << 8));
+}
+uint16_t pack_arc(int cx, int cy, int hor, int ver, int convex) {
+    return (uint16_t)(1u | (cx << 2) | (cy << 4) | ((hor > 0) << 6) | ((ver > 0) << 7) | ((convex != 0) << 8));
+}
+
+bool tile_special(int t, uint16_t &seg) {
+    switch (t) {
+        case 6: seg = pack_linear(0, 2, 2, 0); return true;
+        case 7: seg = pack_linear(0, 0, 2, 2); return true;
+        case 8: seg = pack_linear(2, 0, 0, 2); return true;
+        case 9: seg = pack_linear(2, 2, 0, 0); return true;
+        case 10: seg = pack_arc(0, 0, 1, 1, 1); return true;
+        case 11: seg = pack_arc(2, 0, -1, 1, 1); return true;
+        case 12: seg = pack_arc(2, 2, -1, -1, 1); return true;
+        case 13: seg = pack_arc(0, 2, 1, -1, 1); return true;
+        case 14: seg = pack_arc(2, 2, -1, -1, 0); return true;
+        case 15: seg = pack_arc(0, 2, 1, -1, 0); return true;
+        case 16: seg = pack_arc(0, 0, 1, 1, 0); return true;
+        case 17: seg = pack_arc(2, 0, -1, 1, 0); return true;
+        case 18: seg = pack_linear(0, 1, 2, 0); return true;
+        case 19: seg = pack_linear(0, 0, 2, 1); return true;
+        case 20: seg = pack_linear(2, 1, 0, 2); return true;
+        case 21: seg = pack_linear(2, 2, 0, 1); return true;
+        case 22: seg = pack_linear(0, 2, 2, 1); return true;
+        case 23: seg = pack_linear(0, 1, 2, 2); return true;
+        case 24: seg = pack_linear(2, 0, 0, 1); return true;
+        case 25: seg = pack_linear(2, 1, 0, 0); return true;
+        case 26: seg = pack_linear(0, 2, 1, 0); return true;
+        case 27: seg = pack_linear(1, 0, 2, 2); return true;
+        case 28: seg = pack_linear(2, 0, 1, 2); return true;
+        case 29: seg = pack_linear(1, 2, 0, 0); return true;
+        case 30: seg = pack_linear(1, 2, 2, 0); return true;
+        case 31: seg = pack_linear(0, 0, 1, 2); return true;
+        case 32: seg = pack_linear(1, 0, 0, 2); return true;
+        case 33: seg = pack_linear(2, 2, 1, 0); return true;
+        default: return false;
+    }
+}
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct RawEnt {
+    uint32_t kind;
+    double x, y;
+    int cell;
+    uint32_t init;
+    int link_raw;  // index into raw list (door of a switch), -1 otherwise
+};
+
+void seg_bounds_units(uint16_t s, int &x0, int &y0, int &x1, int &y1) {
+    if ((s & 1u) == 0) {
+        int ax = (s >> 2) & 3, ay = (s >> 4) & 3, bx = (s >> 6) & 3, by = (s >> 8) & 3;
+        x0 = std::min(ax, bx); x1 = std::max(ax, bx);
+        y0 = std::min(ay, by); y1 = std::max(ay, by);
+    } else {
+        // entities.py:119-125: centre, centre + 24*hor, centre + 24*ver
+        int cx = (s >> 2) & 3, cy = (s >> 4) & 3;
+        int hx = cx + (((s >> 6) & 1) ? 2 : -2), vy = cy + (((s >> 7) & 1) ? 2 : -2);
+        x0 = std::min(cx, hx); x1 = std::max(cx, hx);
+        y0 = std::min(cy, vy); y1 = std::max(cy, vy);
+    }
+}
+
+}  // namespace
+
+bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &err) {
+    if (n < 1233) {
+        err = "map_data shorter than 1233 values";
+        return false;
+    }
+    L = CompiledLevel();
+    // ---- tiles: map_data[184:1150] is the 42x23 interior, index x + 42*y; border cells are solid (map_loader.py:22-37)
+    L.tiles.assign(N_CELLS, 1);
+    for (int x = 0; x < 42; x++)
+        for (int y = 0; y < 23; y++) {
+            double v = map[184 + x + 42 * y];
+            int t = (v == std::floor(v) && v >= 0 && v <= 254) ? (int)v : 255;
+            L.tiles[(x + 1) * GRID_H + (y + 1)] = (uint8_t)t;
+        }
+    // ---- accumulate signed half-edges on the 89x51 half-cell lattice (tile_segment_factory.py:190-208)
+    static thread_local int8_t hsum[89][51], vsum[89][51];
+    std::memset(hsum, 0, sizeof(hsum));
+    std::memset(vsum, 0, sizeof(vsum));
+    std::vector<std::vector<uint16_t>> cell(N_CELLS);
+    for (int x = 0; x < GRID_W; x++)
+        for (int y = 0; y < GRID_H; y++) {
+            int t = L.tiles[x * GRID_H + y];
+            if (t == 0 || t >= 34) continue;  // 34..37 glitched tiles are empty (tile_segment_factory.py:184-186)
+            uint16_t ng = ORTHO_NEG[t], ps = ORTHO_POS[t];
+            for (int k = 0; k < 6; k++) {
+                int s = ((ps >> k) & 1) - ((ng >> k) & 1);
+                hsum[2 * x + (k & 1)][2 * y + (k >> 1)] += (int8_t)s;
+            }
+            for (int k = 0; k < 6; k++) {
+                int s = ((ps >> (k + 6)) & 1) - ((ng >> (k + 6)) & 1);
+                vsum[2 * x + (k >> 1)][2 * y + (k & 1)] += (int8_t)s;
+            }
+            uint16_t sp;
+            if (tile_special(t, sp)) cell[x * GRID_H + y].push_back(sp);  // always first in its cell
+        }
+    // ---- surviving half-edges become segments owned by a cell (tile_segment_factory.py:231-262); the lattice is
+    //      walked x-major because the reference pre-seeds its dicts that way (nsim.py:218-219)
+    for (int xc = 0; xc < 89; xc++)
+        for (int yc = 0; yc < 51; yc++) {
+            int st = hsum[xc][yc];
+            if (st == 0) continue;
+            int cx = (int)std::floor(xc / 2.0);
+            int cy = (int)std::floor((yc - 0.1 * st) / 2);
+            if (cx < 0 || cx >= GRID_W || cy < 0 || cy >= GRID_H) continue;
+            int ux = xc - 2 * cx, uy = yc - 2 * cy;  // units of 12 px inside the owning cell
+            cell[cx * GRID_H + cy].push_back(st == -1 ? pack_linear(ux + 1, uy, ux, uy) : pack_linear(ux, uy, ux + 1, uy));
+        }
+    for (int xc = 0; xc < 89; xc++)
+        for (int yc = 0; yc < 51; yc++) {
+            int st = vsum[xc][yc];
+            if (st == 0) continue;
+            int cx = (int)std::floor((xc - 0.1 * st) / 2);
+            int cy = (int)std::floor(yc / 2.0);
+            if (cx < 0 || cx >= GRID_W || cy < 0 || cy >= GRID_H) continue;
+            int ux = xc - 2 * cx, uy = yc - 2 * cy;
+            cell[cx * GRID_H + cy].push_back(st == -1 ? pack_linear(ux, uy, ux, uy + 1) : pack_linear(ux, uy + 1, ux, uy));
+        }
+    L.seg_start.assign(N_CELLS + 1, 0);
+    L.cell_bounds.assign(N_CELLS, 0);
+    for (int c = 0; c < N_CELLS; c++) {
+        L.seg_start[c] = (uint16_t)L.segs.size();
+        int bx0 = 3, by0 = 3, bx1 = 0, by1 = 0;
+        for (uint16_t s : cell[c]) {
+            int x0, y0, x1, y1;
+            seg_bounds_units(s, x0, y0, x1, y1);
+            if (x0 < 0 || y0 < 0 || x1 > 2 || y1 > 2) {
+                err = "internal: segment leaves its cell";
+                return false;
+            }
+            bx0 = std::min(bx0, x0); by0 = std::min(by0, y0);
+            bx1 = std::max(bx1, x1); by1 = std::max(by1, y1);
+            L.segs.push_back(s);
+        }
+        if (!cell[c].empty()) L.cell_bounds[c] = (uint8_t)(bx0 | (by0 << 2) | (bx1 << 4) | (by1 << 6));
+    }
+    if (L.segs.size() > 65000) {
+        err = "too many segments";
+        return false;
+    }
+    L.seg_start[N_CELLS] = (uint16_t)L.segs.size();
+
+    // ---- entities (map_loader.py:84-141, entity_factory.py:145-233)
+    L.spawn_x = map[1231] * 6;
+    L.spawn_y = map[1232] * 6;
+    std::vector<RawEnt> raw;
+    auto cell_of = [](double px, double py) {
+        int cx = clampi((int)std::fmax(std::fmin(std::floor(px / 24), 1e6), -1e6), 0, 43);
+        int cy = clampi((int)std::fmax(std::fmin(std::floor(py / 24), 1e6), -1e6), 0, 24);
+        return cx * GRID_H + cy;
+    };
+    int64_t index = 1230;
+    const double exit_count = n > 1156 ? map[1156] : 0;
+    int last_switch_raw = -1;
+    while (index < n) {
+        if (index + 4 >= n) break;
+        double tv = map[index];
+        int type = (tv == std::floor(tv) && tv >= 0 && tv < 64) ? (int)tv : -1;
+        double xc = map[index + 1], yc = map[index + 2];
+        if (type == 1 || type == 21) {
+            // type 1 starts toggled/deadly (state 0), type 21 starts untoggled (state 1): entity_factory.py:181-182,230-231
+            raw.push_back({EK_MINE, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), type == 1 ? 0u : 1u, -1});
+            L.n_thinkable++;
+        } else if (type == 2) {
+            raw.push_back({EK_GOLD, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 1u, -1});
+        } else if (type == 3) {
+            int64_t ci = index + 5 * (int64_t)exit_count;
+            if (ci + 2 >= n || ci < 0) {
+                err = "exit switch coordinates out of range";
+                return false;
+            }
+            double sx = map[ci + 1] * 6, sy = map[ci + 2] * 6;
+            raw.push_back({EK_EXIT, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 0u, -1});
+            raw.push_back({EK_SWITCH, sx, sy, cell_of(sx, sy), 1u, (int)raw.size() - 1});
+            last_switch_raw = (int)raw.size() - 1;
+        } else if (type == 6) {
+            // the entity lives at its switch (entity_door_base.py:94-97); its door segment never reaches the
+            // ninja's region queries because the spatial index is snapshotted before entities load
+            if (index + 7 >= n) {
+                err = "locked door record truncated";
+                return false;
+            }
+            double sx = map[index + 6] * 6, sy = map[index + 7] * 6;
+            raw.push_back({EK_LOCKED, sx, sy, cell_of(sx, sy), 1u, -1});
+        } else if (type == 5 || type == 8 || type == 10 || type == 11 || type == 14 || type == 17 || type == 20 ||
+                   type == 24 || type == 25 || type == 26 || type == 28) {
+            L.unsupported_mask |= 1u << type;
+        }
+        if (type == 6 || type == 8) {
+            if (index + 9 < n && map[index + 7] != 0 && map[index + 8] == 0 && map[index + 9] == 0)
+                index += 10;
+            else
+                index += 9;
+        } else {
+            index += 5;
+        }
+    }
+    if (raw.size() > 4096) {
+        err = "too many entities (max 4096 per level)";
+        return false;
+    }
+    // CSR by cell: map order inside a cell, exit doors after everything else of that cell (they are appended to
+    // the cell's list only when their switch is hit, entity_exit_switch.py:120)
+    std::vector<int> order(raw.size());
+    for (size_t i = 0; i < raw.size(); i++) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        int ka = raw[a].cell * 2 + (raw[a].kind == EK_EXIT), kb = raw[b].cell * 2 + (raw[b].kind == EK_EXIT);
+        return ka < kb;
+    });
+    std::vector<int> slot_of(raw.size());
+    for (size_t s = 0; s < order.size(); s++) slot_of[order[s]] = (int)s;
+    size_t ne = raw.size();
+    L.ent_x.resize(ne); L.ent_y.resize(ne); L.ent_meta.resize(ne); L.ent_map_order.resize(ne);
+    L.ent_start.assign(N_CELLS + 1, 0);
+    L.ent_init_words.assign((ne + 15) / 16, 0);
+    std::vector<int> count(N_CELLS, 0);
+    for (size_t s = 0; s < ne; s++) {
+        const RawEnt &r = raw[order[s]];
+        L.ent_x[s] = r.x;
+        L.ent_y[s] = r.y;
+        uint32_t link = r.link_raw >= 0 ? (uint32_t)slot_of[r.link_raw] : 0xffffu;
+        L.ent_meta[s] = r.kind | (r.init << 4) | (link << 8);
+        L.ent_init_words[s >> 4] |= r.init << ((s & 15) * 2);
+        count[r.cell]++;
+    }
+    for (size_t i = 0; i < ne; i++) L.ent_map_order[i] = (uint16_t)slot_of[i];
+    int acc = 0;
+    for (int c = 0; c < N_CELLS; c++) {
+        L.ent_start[c] = (uint16_t)acc;
+        acc += count[c];
+    }
+    L.ent_start[N_CELLS] = (uint16_t)acc;
+    if (last_switch_raw >= 0) {
+        L.obs_switch = slot_of[last_switch_raw];
+        L.obs_door = slot_of[raw[last_switch_raw].link_raw];
+    }
+    return true;
+}
+
+int dump_segments(const CompiledLevel &lv, int16_t *out, int max_rows) {
+    int r = 0;
+    for (int c = 0; c < N_CELLS; c++) {
+        int cx = c / GRID_H, cy = c % GRID_H;
+        for (int i = lv.seg_start[c]; i < lv.seg_start[c + 1]; i++) {
+            if (r >= max_rows) return -1;
+            uint16_t s = lv.segs[i];
+            int16_t *o = out + 8 * r++;
+            o[0] = (int16_t)cx; o[1] = (int16_t)cy; o[2] = (int16_t)(s & 1);
+            if ((s & 1) == 0) {
+                o[3] = (int16_t)(24 * cx + 12 * ((s >> 2) & 3)); o[4] = (int16_t)(24 * cy + 12 * ((s >> 4) & 3));
+                o[5] = (int16_t)(24 * cx + 12 * ((s >> 6) & 3)); o[6] = (int16_t)(24 * cy + 12 * ((s >> 8) & 3));
+                o[7] = 1;
+            } else {
+                o[3] = (int16_t)(24 * cx + 12 * ((s >> 2) & 3)); o[4] = (int16_t)(24 * cy + 12 * ((s >> 4) & 3));
+                o[5] = (int16_t)(((s >> 6) & 1) ? 1 : -1); o[6] = (int16_t)(((s >> 7) & 1) ? 1 : -1);
+                o[7] = (int16_t)((s >> 8) & 1);
+            }
+        }
+    }
+    return r;
+}
+
+}  // namespace npp

@@ -1,0 +1,48 @@
+// npp_level.hpp -- host-side level compiler: raw map_data -> packed per-cell tables for the HIP kernels.
+//
+// Replaces, for the accelerated path, the reference's level-load chain
+//   nclone/map_loader.py:18-145 (tiles, entities), nclone/utils/tile_segment_factory.py:170-262
+//   (tile -> segments with ortho cancellation), nclone/utils/spatial_segment_index.py:69-110
+//   (per-cell snapshot + cell AABB), nclone/utils/entity_factory.py:145-233, nclone/entities.py:209-236.
+// Output layout is documented in DESIGN.md ("level tables").
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace npp {
+
+constexpr int GRID_W = 44;
+constexpr int GRID_H = 25;
+constexpr int N_CELLS = GRID_W * GRID_H;  // cell index = cx * 25 + cy  (x-major, like the reference's queries)
+
+// entity kinds understood by the kernels (low nibble of ent_meta)
+enum EntKind : uint32_t { EK_NONE = 0, EK_MINE = 1, EK_GOLD = 2, EK_EXIT = 3, EK_SWITCH = 4, EK_LOCKED = 6 };
+
+// Packed collision segment (uint16), coordinates in units of 12 px relative to the owning cell's origin:
+//   linear : bit0 = 0, bits 2-3 x1, 4-5 y1, 6-7 x2, 8-9 y2
+//   arc    : bit0 = 1, bits 2-3 cx, 4-5 cy, bit6 hor>0, bit7 ver>0, bit8 convex
+// Packed cell bounds (uint8): bits 0-1 min x, 2-3 min y, 4-5 max x, 6-7 max y (same units).
+struct CompiledLevel {
+    std::vector<uint16_t> seg_start;   // [N_CELLS+1] CSR over cells
+    std::vector<uint16_t> segs;        // packed, query order
+    std::vector<uint8_t> cell_bounds;  // [N_CELLS]
+    std::vector<uint16_t> ent_start;   // [N_CELLS+1] CSR over cells, map order inside a cell, exit doors last
+    std::vector<double> ent_x, ent_y;  // [n_ent] pixel positions (coord * 6)
+    std::vector<uint32_t> ent_meta;    // [n_ent] kind | init2bit << 4 | link << 8 (switch -> its door's index)
+    std::vector<uint16_t> ent_map_order;  // [n_ent] CSR slot of the i-th entity in map order (for dumps)
+    std::vector<uint32_t> ent_init_words;  // 2 bits per entity, 16 per word
+    std::vector<uint8_t> tiles;        // [N_CELLS] tile id per cell (border = 1), for the rasteriser
+    double spawn_x = 0, spawn_y = 0;
+    int obs_switch = -1, obs_door = -1;  // CSR slots of the exit switch / door reported in observations
+    int n_thinkable = 0;               // mines
+    uint32_t unsupported_mask = 0;     // bit t set if entity type t present but not simulated
+};
+
+// Returns false (and fills err) on malformed input.
+bool compile_level(const double *map, int64_t n, CompiledLevel &out, std::string &err);
+
+// rows of 8 int16, see npp_dump_level_segments in npp_amd.h
+int dump_segments(const CompiledLevel &lv, int16_t *out, int max_rows);
+
+}  // namespace npp
