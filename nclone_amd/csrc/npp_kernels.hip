@@ -808,7 +808,8 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         const int act = a.n_ticks > 0 ? a.inputs[e] : 0;
         const int hor = (act == 1 || act == 4) ? -1 : ((act == 2 || act == 5) ? 1 : 0);   // :366-402
         const int jump = act >= 3 ? 1 : 0;
-        bool live = valid;
+        // an env that is already terminal (no auto-reset) is not stepped again until the caller resets it
+        bool live = valid && !(n.state == 8 || n.state == 6 || n.state == 7);
         for (int t = 0; t < a.n_ticks; t++) {
             if (live) {
                 sim_tick(lv, n, ew, lane, hor, jump);

@@ -45,6 +45,7 @@ def test_replays_match_reference_tick_for_tick(golden):
     worst = 0.0
     exact = 0
     total = 0
+    final = c["final"]
     for tick in range(tmax):
         b.tick(d_inputs[tick : tick + 1])
         f, di = b.dump_state()
@@ -52,6 +53,10 @@ def test_replays_match_reference_tick_for_tick(golden):
         for k, i in enumerate(idx):
             if tick >= T[k]:
                 continue
+            if tick == T[k] - 1:
+                # end-state table of the survey: ticks run, final ninja state, final position
+                assert int(final[i, 0]) == T[k] and di[k, 0] == int(final[i, 1])
+                assert np.array_equal(f[k, :2], final[i, 2:4])
             ref = t["t%d" % i][tick]
             total += 1
             d32 = np.abs(f[k, :4].astype(np.float32).astype(np.float64) - ref.astype(np.float32).astype(np.float64)).max()
@@ -62,11 +67,6 @@ def test_replays_match_reference_tick_for_tick(golden):
                 diverged += 1
     print("replay ticks %d, bit-exact fp64 ticks %d, worst f32 position diff %.3g, divergent ticks %d" % (total, exact, worst, diverged))
     assert diverged == 0
-    # end state table of the survey (win tick / final position)
-    final = c["final"]
-    f, di = b.dump_state()
-    for k, i in enumerate(idx):
-        assert di[k, 0] == int(final[i, 1])
 
 
 def test_replays_bit_exact_vs_oracle_mul(golden, oracle_mod):
