@@ -50,6 +50,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so) and publishes its symbols globally; it must be
+    # loaded BEFORE this library so that both share ONE runtime (streams and device pointers are exchanged).
+    import torch  # noqa: F401
+
     if not os.path.isfile(LIB_PATH):
         raise NativeLibraryMissing(
             "nclone_amd: %s not found. Build it with `python -m nclone_amd.build_native` (needs hipcc). "
