@@ -142,6 +142,12 @@ int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int m
                                uint32_t *unsupported_mask);
 int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out);
 
+/* Launch geometry: lanes_per_env wavefront lanes cooperate on one environment (power of two, 1..64; 0 = choose from
+ * n_envs so that the grid fills the chip), waves_per_block wavefronts share one LDS copy of a level (1..4, 0 = auto).
+ * Results are bit-identical for every geometry; only speed changes. */
+int npp_set_launch_geometry(npp_handle h, int lanes_per_env, int waves_per_block);
+int npp_get_launch_geometry(npp_handle h, int *lanes_per_env, int *waves_per_block);
+
 int npp_num_envs(npp_handle h);
 int npp_num_levels(npp_handle h);
 

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,7 +27,12 @@ struct npp_handle_s {
     unsigned char *d_blob = nullptr;
     LevelHdr *d_hdr = nullptr;
     int n_words_max = 1;
-    uint32_t lds_hot_cap = 0;
+    uint32_t hot_max = 0;      // largest staged-level size over the loaded set
+    uint32_t lds_hot_cap = 0;  // LDS bytes reserved for a staged level under the current launch geometry
+    int lanes_per_env = 0;     // 0 = choose from n_envs
+    int waves_per_block = 0;
+    int geo_g = 1, geo_wpb = 1;
+    int lds_level = 0;         // all workgroups level-uniform and staged levels fit
     std::vector<CompiledLevel> levels;
     std::vector<LevelHdr> hdrs;
     std::vector<int32_t> env_level;
@@ -52,6 +58,50 @@ int fail(npp_handle h, int code, const std::string &msg) {
 
 uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
+// Launch geometry (DESIGN.md "lanes per environment"): G lanes cooperate on one env.  The chip has 256 CUs x 4 SIMDs;
+// the path is a latency-bound fp64 dependency chain, so the grid is sized to put about two wavefronts on every SIMD
+// (one hides the other's latency) and the spare lanes of each wavefront are spent on segment-level parallelism.
+void plan_geometry(npp_handle h) {
+    int g = h->lanes_per_env;
+    if (const char *ev = std::getenv("NPP_LANES_PER_ENV")) g = std::atoi(ev);
+    if (g <= 0) {
+        g = 16;
+        while (g > 1 && (long long)h->n * g / 64 > 2048) g >>= 1;
+    }
+    int gg = 1;
+    while (gg * 2 <= g && gg < 64) gg *= 2;
+    g = gg;
+    int wpb = h->waves_per_block;
+    if (const char *ev = std::getenv("NPP_WAVES_PER_BLOCK")) wpb = std::atoi(ev);
+    if (wpb <= 0) wpb = 4;
+    if (wpb > 4) wpb = 4;
+    while (wpb > 1 && (64 / g) * wpb > h->n) wpb >>= 1;
+    // LDS plan: staged level + entity words + observation staging must fit the per-workgroup budget
+    for (;;) {
+        int epb = (64 / g) * wpb;
+        uint32_t fixed = (uint32_t)h->n_words_max * epb * 4 + (uint32_t)epb * 41 * 4;
+        uint32_t cap = h->hot_max;
+        if (fixed + cap > LDS_BUDGET) cap = fixed < LDS_BUDGET ? ((LDS_BUDGET - fixed) / 16) * 16 : 0;
+        if (fixed + cap <= LDS_BUDGET || wpb == 1) {
+            h->lds_hot_cap = cap;
+            break;
+        }
+        wpb >>= 1;
+    }
+    h->geo_g = g;
+    h->geo_wpb = wpb;
+    // can every workgroup stage ONE level?  (the host owns the env -> level assignment)
+    int epb = (64 / g) * wpb;
+    int ok = !h->hdrs.empty();
+    for (int b0 = 0; b0 < h->n && ok; b0 += epb) {
+        int lvl = h->env_level[b0];
+        if (h->hdrs[lvl].hot_bytes > h->lds_hot_cap) ok = 0;
+        for (int e = b0 + 1; e < b0 + epb && e < h->n && ok; e++)
+            if (h->env_level[e] != lvl) ok = 0;
+    }
+    h->lds_level = ok;
+}
+
 KernelArgs base_args(npp_handle h) {
     KernelArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -66,6 +116,9 @@ KernelArgs base_args(npp_handle h) {
     a.autoreset = (h->flags & NPP_FLAG_AUTORESET) ? 1 : 0;
     a.n_words_max = h->n_words_max;
     a.lds_hot_cap = h->lds_hot_cap;
+    a.lanes_per_env = h->geo_g;
+    a.waves_per_block = h->geo_wpb;
+    a.lds_level = h->lds_level;
     return a;
 }
 
@@ -138,6 +191,23 @@ int npp_sync(npp_handle h) {
     return NPP_OK;
 }
 
+int npp_set_launch_geometry(npp_handle h, int lanes_per_env, int waves_per_block) {
+    if (!h) return NPP_ERR_INVALID;
+    if (lanes_per_env < 0 || lanes_per_env > 64 || (lanes_per_env & (lanes_per_env - 1)) || waves_per_block < 0 || waves_per_block > 4)
+        return fail(h, NPP_ERR_INVALID, "npp_set_launch_geometry: lanes_per_env must be 0 or a power of two <= 64, waves_per_block 0..4");
+    h->lanes_per_env = lanes_per_env;
+    h->waves_per_block = waves_per_block;
+    plan_geometry(h);
+    return NPP_OK;
+}
+
+int npp_get_launch_geometry(npp_handle h, int *lanes_per_env, int *waves_per_block) {
+    if (!h) return NPP_ERR_INVALID;
+    if (lanes_per_env) *lanes_per_env = h->geo_g;
+    if (waves_per_block) *waves_per_block = h->geo_wpb;
+    return NPP_OK;
+}
+
 int npp_num_envs(npp_handle h) { return h ? h->n : 0; }
 int npp_num_levels(npp_handle h) { return h ? (int)h->levels.size() : 0; }
 
@@ -200,14 +270,6 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.fits_lds = 1;
         hot_max = std::max(hot_max, hot_bytes);
     }
-    // LDS plan: staged level + entity words + observation staging must fit the per-workgroup budget
-    uint32_t fixed = (uint32_t)words_max * BLOCK * 4 + BLOCK * 41 * 4;
-    uint32_t hot_cap = hot_max;
-    if (fixed + hot_cap > LDS_BUDGET) {
-        hot_cap = fixed < LDS_BUDGET ? ((LDS_BUDGET - fixed) / 16) * 16 : 0;
-        for (auto &H : hdrs) H.fits_lds = H.hot_bytes <= hot_cap ? 1 : 0;
-    }
-    if (fixed + hot_cap > 160 * 1024) return fail(h, NPP_ERR_INVALID, "npp_load_levels: entity tables exceed LDS");
     // ---- upload (replaces the previous set)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(h->d_blob); h->d_blob = nullptr;
@@ -222,7 +284,11 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     h->levels.swap(lv);
     h->hdrs.swap(hdrs);
     h->n_words_max = words_max;
-    h->lds_hot_cap = hot_cap;
+    h->hot_max = hot_max;
+    std::fill(h->env_level.begin(), h->env_level.end(), 0);
+    plan_geometry(h);
+    if (lds_bytes(h->lds_hot_cap, h->n_words_max, (64 / h->geo_g) * h->geo_wpb) > 160 * 1024)
+        return fail(h, NPP_ERR_INVALID, "npp_load_levels: entity tables exceed LDS");
     std::fill(h->env_level.begin(), h->env_level.end(), 0);
     HIP_TRY(h, hipMemset(h->d_env_level, 0, sizeof(int32_t) * (size_t)h->n));
     return npp_reset(h, nullptr);
@@ -240,6 +306,7 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
         h->env_level[e] = level_ids[i];
         mask[e] = 1;
     }
+    plan_geometry(h);
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_env_level, h->env_level.data(), sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));

@@ -64,15 +64,20 @@ struct KernelArgs {
     int mode;             // 0 gym step, 1 raw ticks
     int autoreset;
     int n_words_max;
+    int lanes_per_env;    // G
+    int waves_per_block;  // WPB
     uint32_t lds_hot_cap; // bytes reserved for a staged level
+    int lds_level;        // 1: every workgroup is level-uniform and its level fits lds_hot_cap -> stage it in LDS
     StepOut out;
 };
 
-constexpr int BLOCK = 64;  // one wavefront per workgroup: one lane per environment
+constexpr int WAVE = 64;
 
-// dynamic LDS layout: [hot_cap][ent words: n_words_max * 64 * 4][obs staging: 64 * 41 * 4]
-inline size_t lds_bytes(uint32_t hot_cap, int n_words_max) {
-    return (size_t)hot_cap + (size_t)n_words_max * BLOCK * 4 + (size_t)BLOCK * 41 * 4;
+// Launch geometry: G lanes cooperate on one environment (G in {1,2,4,8,16,32,64}); a wavefront holds 64/G envs; a
+// workgroup holds WPB wavefronts that share one LDS copy of a level when all their envs play the same level.
+// dynamic LDS layout: [hot_cap][ent words: n_words_max * envs_per_block * 4][obs staging: envs_per_block * 41 * 4]
+inline size_t lds_bytes(uint32_t hot_cap, int n_words_max, int envs_per_block) {
+    return (size_t)hot_cap + (size_t)n_words_max * envs_per_block * 4 + (size_t)envs_per_block * 41 * 4;
 }
 
 hipError_t launch_step(const KernelArgs &a, hipStream_t s);

@@ -1,16 +1,21 @@
 // npp_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) of the batched N++ tick.
 //
-// One wavefront lane per environment; one 64-lane wavefront per workgroup.  The ninja state lives in registers
-// for the whole step (frame_skip ticks per launch), SoA planes in HBM are read and written once per launch with
-// coalesced 512-byte wave accesses.  A workgroup whose 64 envs play the same level stages that level's packed
-// collision table (CSR over cells + 16-bit segments + 8-bit cell bounds, ~11 KB) into LDS; per-env entity bits
-// (2 bits per entity) are kept in LDS for the launch as well.  Observations are assembled in LDS and written
-// with contiguous wave stores.  No MFMA: there is no dense contraction on this path (fp64 scalar chains).
+// G wavefront lanes cooperate on one environment (G = 1..64, chosen per launch from the env count so that the
+// grid fills the 1024 SIMDs of the chip): the lanes of a group hold the same ninja state in registers, split the
+// per-segment work of every region query between them and combine with DPP butterflies.  The state lives in
+// registers for the whole step (frame_skip ticks per launch); SoA planes in HBM are read and written once per
+// launch.  A workgroup whose envs all play the same level stages that level's packed collision table (CSR over
+// cells + 16-bit segments + 8-bit cell bounds, ~11 KB) into LDS; per-env entity bits (2 bits per entity) are kept
+// in LDS for the launch as well.  Observations are assembled in LDS and written with contiguous stores.
+// No MFMA: there is no dense contraction on this path (fp64 scalar chains).
 //
 // Arithmetic contract: IEEE fp64, no fused contraction (the reference is CPython float arithmetic); every
 // comparison keeps the reference's strictness and operand order.  Reference citations are file:line in
 // /root/reference/nclone/.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "npp_internal.hpp"
 #include "npp_level.hpp"
@@ -44,6 +49,28 @@ constexpr double DIR26S = 0x1.c9f25c5bfedd9p-2;  // 12 / sqrt(720)
 
 #define DEV __device__ __forceinline__
 
+// Diagnostic build only (-DNPP_STAMPS, tools/stamp_profile.py): per-phase shader-clock totals accumulated by lane 0
+// of every wavefront.  The shipped library is built without it (no stamp executes).
+#ifdef NPP_STAMPS
+constexpr int N_STAMP = 12;
+__device__ unsigned long long g_stamps[N_STAMP * 16384];   // [wave][phase], written once per wave per launch
+struct Stamps { unsigned long long acc[N_STAMP]; unsigned long long t0; };
+#define STAMP_ARG , Stamps &st
+#define STAMP_PASS , st
+#define STAMP_INIT st.t0 = __builtin_amdgcn_s_memtime()
+#define STAMP(i)                                                       \
+    do {                                                               \
+        unsigned long long _t1 = __builtin_amdgcn_s_memtime();         \
+        st.acc[i] += _t1 - st.t0;                                      \
+        st.t0 = __builtin_amdgcn_s_memtime();                          \
+    } while (0)
+#else
+#define STAMP_ARG
+#define STAMP_PASS
+#define STAMP_INIT do { } while (0)
+#define STAMP(i) do { } while (0)
+#endif
+
 struct Nj {
     double x, y, vx, vy, vxo, vyo, fnx, fny, cnx, cny;
     int state, airborn, airborn_old, walled, wn, jio, hor, jump, gjump, dslow;
@@ -71,11 +98,29 @@ DEV double dsqrt(double v) { return __builtin_sqrt(v); }
 DEV double pymin(double a, double b) { return b < a ? b : a; }  // Python min(a, b)
 DEV double pymax(double a, double b) { return b > a ? b : a; }  // Python max(a, b)
 
-DEV int cell_coord(double p, int hi) {
-    double q = __builtin_floor(p / 24.0);
-    q = q < 0.0 ? 0.0 : q;          // also maps NaN to 0
-    q = q > (double)hi ? (double)hi : q;
-    return (int)q;
+// floor(p / 12) as an integer, exactly, without an fp64 division: the reciprocal product is off by at most one
+// and is fixed up with exact comparisons (12 * k is exact).  floor(fl(p / 24)) of the reference equals the true
+// floor(p / 24) for every double p (a p just below 24 k is at least 16 ulp(k) below it, so p / 24 cannot round up
+// to k), and floor(p / 24) == floor(floor(p / 12) / 2).
+DEV int floor12(double p) {
+    double q = __builtin_floor(p * (1.0 / 12.0));
+    q = q < -1.0e6 ? -1.0e6 : q;    // also maps NaN down
+    q = q > 1.0e6 ? 1.0e6 : q;
+    int k = (int)q;
+    double lo = 12.0 * k;
+    k = (lo > p) ? k - 1 : ((lo + 12.0 <= p) ? k + 1 : k);
+    return k;
+}
+DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+DEV int cell_coord(double p, int hi) { return clampi(floor12(p) >> 1, 0, hi); }   // clamp(floor(p / 24), 0, hi)
+
+// a / b for a constant b with y = RN(1 / b): Markstein's correction gives the correctly rounded quotient
+// (checked against IEEE division on 1.2e9 operands for b in {144, 720, 1152}; tests/test_gpu_parity.py re-checks
+// the whole path bit-for-bit against the oracle's true divisions).
+DEV double div_const(double a, double b, double y) {
+    double q = a * y;
+    double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, y, q);
 }
 
 // ---- state planes <-> registers -------------------------------------------------------------------------------
@@ -130,12 +175,14 @@ DEV void spawn_state(const Lv &lv, Nj &n) {
     n.pcell = cell_coord(n.x, 43) * 25 + cell_coord(n.y, 24);
 }
 
-// ---- entity bits in LDS: word w of lane l at ew[w * 64 + l] ----------------------------------------------------
-DEV uint32_t ent_get(const uint32_t *ew, int lane, int slot) {
-    return (ew[(slot >> 4) * BLOCK + lane] >> ((slot & 15) * 2)) & 3u;
-}
-DEV void ent_set(uint32_t *ew, int lane, int slot, uint32_t v) {
-    uint32_t *p = &ew[(slot >> 4) * BLOCK + lane];
+// ---- entity bits in LDS: word w of the env at w[w * stride] (stride = envs per workgroup) ----------------------------
+struct EntBits {
+    uint32_t *w;
+    int stride;
+};
+DEV uint32_t ent_get(EntBits eb, int slot) { return (eb.w[(slot >> 4) * eb.stride] >> ((slot & 15) * 2)) & 3u; }
+DEV void ent_set(EntBits eb, int slot, uint32_t v) {
+    uint32_t *p = &eb.w[(slot >> 4) * eb.stride];
     int sh = (slot & 15) * 2;
     *p = (*p & ~(3u << sh)) | (v << sh);
 }
@@ -236,7 +283,12 @@ DEV bool seg_closest(uint32_t s, int xc, int yc, double px, double py, double &a
         double x1 = ox + 12.0 * ax, y1 = oy + 12.0 * ay;
         double wx = 12.0 * (bx - ax), wy = 12.0 * (by - ay);
         double dx = px - x1, dy = py - y1;
-        double u = (dx * wx + dy * wy) / (sq(wx) + sq(wy));
+        // seg_lensq is 144 (axis aligned), 1152 (45 degrees) or 720 (the two gentle/steep slopes)
+        int aw = (bx - ax) * (bx - ax) + (by - ay) * (by - ay);   // 1, 8 or 5 in units of 144
+        double num = dx * wx + dy * wy;
+        double u = aw == 1 ? div_const(num, 144.0, 1.0 / 144.0)
+                 : (aw == 8 ? div_const(num, 1152.0, 1.0 / 1152.0)
+                 : (aw == 5 ? div_const(num, 720.0, 1.0 / 720.0) : num / (sq(wx) + sq(wy))));
         u = pymax(u, 0.0);
         u = pymin(u, 1.0);
         a = x1 + u * wx;
@@ -281,16 +333,215 @@ DEV void seg_aabb(uint32_t s, int xc, int yc, double &x0, double &y0, double &x1
     y0 = 24.0 * yc + 12.0 * uy0; y1 = 24.0 * yc + 12.0 * uy1;
 }
 
+// ---- cooperative groups of G lanes per environment -------------------------------------------------------------
+// All G lanes of a group hold the same ninja state and execute the same scalar code redundantly; they split up only
+// the per-segment work of a region query (lane r takes segments r, r+G, ... of the query's flat order) and combine
+// with DPP butterflies.  Order-dependent semantics of the reference are preserved exactly: minima are
+// order-independent, "first wins" ties (physics.py:176 strict <) are broken by the flat query index, and the wall
+// probe's sum (ninja.py:441) is accumulated in query order.
+template <int CTRL> DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> DEV double dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = dpp_i<CTRL>(lo);
+    hi = dpp_i<CTRL>(hi);
+    return __hiloint2double(hi, lo);
+}
+// value held by the butterfly partner at distance STEP (1,2: quad_perm; 4: row_half_mirror; 8: row_mirror)
+template <int STEP> DEV int partner_i(int v) {
+    if constexpr (STEP == 1) return dpp_i<0xB1>(v);
+    else if constexpr (STEP == 2) return dpp_i<0x4E>(v);
+    else if constexpr (STEP == 4) return dpp_i<0x141>(v);
+    else if constexpr (STEP == 8) return dpp_i<0x140>(v);
+    else return __shfl_xor(v, STEP, 64);
+}
+template <int STEP> DEV double partner_d(double v) {
+    if constexpr (STEP == 1) return dpp_d<0xB1>(v);
+    else if constexpr (STEP == 2) return dpp_d<0x4E>(v);
+    else if constexpr (STEP == 4) return dpp_d<0x141>(v);
+    else if constexpr (STEP == 8) return dpp_d<0x140>(v);
+    else return __shfl_xor(v, STEP, 64);
+}
+
+template <int G, int STEP = 1> DEV double group_min(double t) {
+    if constexpr (STEP < G) {
+        double o = partner_d<STEP>(t);
+        if (o < t) t = o;
+        return group_min<G, STEP * 2>(t);
+    } else {
+        return t;
+    }
+}
+
+struct Best {
+    double key;   // biased squared distance (physics.py:171-176)
+    int idx;      // flat query index * 2 + is_back_facing
+    double a, b;  // closest point
+};
+
+template <int G, int STEP = 1> DEV void group_argmin(Best &m) {
+    if constexpr (STEP < G) {
+        double k = partner_d<STEP>(m.key);
+        int i = partner_i<STEP>(m.idx);
+        double a = partner_d<STEP>(m.a), b = partner_d<STEP>(m.b);
+        bool take = (k < m.key) || (k == m.key && i < m.idx);
+        m.key = take ? k : m.key; m.idx = take ? i : m.idx; m.a = take ? a : m.a; m.b = take ? b : m.b;
+        group_argmin<G, STEP * 2>(m);
+    }
+}
+
 // SpatialSegmentIndex.query_region cell filter (utils/spatial_segment_index.py:140-156, inclusive test :186-188)
-DEV bool cell_passes(const Lv &lv, int c, int xc, int yc, double qx0, double qy0, double qx1, double qy1) {
-    uint32_t cb = lv.bounds[c];
+DEV bool cell_passes(uint32_t cb, int xc, int yc, double qx0, double qy0, double qx1, double qy1) {
     double bx0 = 24.0 * xc + 12.0 * (cb & 3), by0 = 24.0 * yc + 12.0 * ((cb >> 2) & 3);
     double bx1 = 24.0 * xc + 12.0 * ((cb >> 4) & 3), by1 = 24.0 * yc + 12.0 * ((cb >> 6) & 3);
     return !(qx1 < bx0 || qx0 > bx1 || qy1 < by0 || qy0 > by1);
 }
 
-// sweep_circle_vs_tiles (physics.py:104-128)
-DEV double sweep_circle_vs_tiles(const Lv &lv, double xo, double yo, double dx, double dy, double radius) {
+// ---- per-tick candidate registers (fast path) ------------------------------------------------------------------
+// Once per tick every lane group gathers ALL segments of the cells around the ninja's path (old position -> new
+// position, inflated by the largest query radius) and keeps them decoded in registers: lane r holds candidates
+// r, r + G, ... of the region's x-major order (K slots per lane).  A region query of the reference (sweep box,
+// depenetration gather box, wall-probe box) whose clamped cell range lies inside the gathered range is then
+// answered from registers by applying the reference's own filters per candidate (cell range, inclusive cell-bounds
+// test, per-segment AABB test) -- the surviving candidates in flat order are exactly the reference's list.  A query
+// that leaves the region (or a region with more segments than lanes x slots) falls back to the LDS walk below.
+template <int G> struct KSlots { static constexpr int value = G >= 32 ? 1 : (G >= 16 ? 2 : 4); };
+
+struct Query {
+    int c0x, c1x, c0y, c1y;   // clamped cell range (utils/spatial_segment_index.py:131-134)
+    int fx1, cx0, fy1, cy0;   // floor(max / 12), ceil(min / 12): the inclusive cell-bounds test (:186-188) in ints
+};
+DEV Query make_query(double qx0, double qy0, double qx1, double qy1) {
+    Query q;
+    int f0x = floor12(qx0), f0y = floor12(qy0);
+    q.fx1 = floor12(qx1);
+    q.fy1 = floor12(qy1);
+    q.cx0 = f0x + ((12.0 * f0x != qx0) ? 1 : 0);
+    q.cy0 = f0y + ((12.0 * f0y != qy0) ? 1 : 0);
+    q.c0x = clampi(f0x >> 1, 0, 43); q.c1x = clampi(q.fx1 >> 1, 0, 43);
+    q.c0y = clampi(f0y >> 1, 0, 24); q.c1y = clampi(q.fy1 >> 1, 0, 24);
+    return q;
+}
+
+template <int K> struct Cand {
+    int rc0x, rc1x, rc0y, rc1y;   // gathered cell range
+    bool ok;
+    uint32_t s[K];      // packed segment (bits 0-15, incl. cell y) | cell x << 16 | valid << 31
+    uint32_t babs[K];   // the owning cell's bounds in absolute 12-px units: x0 | y0 << 8 | x1 << 16 | y1 << 24
+    double x1[K], y1[K], x2[K], y2[K];   // linear: end points; arc: centre, p_hor.x, p_ver.y
+};
+
+template <int G, int K>
+DEV void cand_gather(const Lv &lv, int r, double bx0, double by0, double bx1, double by1, Cand<K> &c) {
+    Query q = make_query(bx0, by0, bx1, by1);
+    c.rc0x = q.c0x; c.rc1x = q.c1x; c.rc0y = q.c0y; c.rc1y = q.c1y;
+    const int ncol = q.c1x - q.c0x + 1;
+    int a0 = lv.seg_start[q.c0x * 25 + q.c0y], n0 = lv.seg_start[q.c0x * 25 + q.c1y + 1] - a0;
+    int a1 = 0, n1 = 0, a2 = 0, n2 = 0;
+    if (ncol > 1) { a1 = lv.seg_start[(q.c0x + 1) * 25 + q.c0y]; n1 = lv.seg_start[(q.c0x + 1) * 25 + q.c1y + 1] - a1; }
+    if (ncol > 2) { a2 = lv.seg_start[(q.c0x + 2) * 25 + q.c0y]; n2 = lv.seg_start[(q.c0x + 2) * 25 + q.c1y + 1] - a2; }
+    const int total = n0 + n1 + n2;
+    c.ok = ncol <= 3 && total <= G * K;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        int f = k * G + r;
+        c.s[k] = 0; c.babs[k] = 0; c.x1[k] = 0; c.y1[k] = 0; c.x2[k] = 0; c.y2[k] = 0;
+        if (c.ok && f < total) {
+            int xc = q.c0x, i = a0 + f;
+            if (f >= n0) { xc += 1; i = a1 + (f - n0); }
+            if (f >= n0 + n1) { xc += 1; i = a2 + (f - n0 - n1); }
+            uint32_t s = lv.segs[i];
+            int yc = s >> 11;
+            uint32_t cb = lv.bounds[xc * 25 + yc];
+            c.s[k] = s | ((uint32_t)xc << 16) | 0x80000000u;
+            c.babs[k] = (2 * xc + (cb & 3)) | ((2 * yc + ((cb >> 2) & 3)) << 8) | ((2 * xc + ((cb >> 4) & 3)) << 16) |
+                        ((2 * yc + ((cb >> 6) & 3)) << 24);
+            double ox = 24.0 * xc, oy = 24.0 * yc;
+            if ((s & 1u) == 0) {
+                c.x1[k] = ox + 12.0 * ((s >> 2) & 3); c.y1[k] = oy + 12.0 * ((s >> 4) & 3);
+                c.x2[k] = ox + 12.0 * ((s >> 6) & 3); c.y2[k] = oy + 12.0 * ((s >> 8) & 3);
+            } else {
+                c.x1[k] = ox + 12.0 * ((s >> 2) & 3); c.y1[k] = oy + 12.0 * ((s >> 4) & 3);
+                c.x2[k] = c.x1[k] + (((s >> 6) & 1) ? 24.0 : -24.0);   // p_hor.x (entities.py:113)
+                c.y2[k] = c.y1[k] + (((s >> 7) & 1) ? 24.0 : -24.0);   // p_ver.y (entities.py:114)
+            }
+        }
+    }
+}
+
+template <int K> DEV bool cand_covers(const Cand<K> &c, const Query &q) {
+    return c.ok && q.c0x >= c.rc0x && q.c1x <= c.rc1x && q.c0y >= c.rc0y && q.c1y <= c.rc1y;
+}
+
+// would the reference's query have returned this candidate?  (cell inside the query's range + cell-bounds test)
+DEV bool cand_in_query(uint32_t sk, uint32_t babs, const Query &q) {
+    int xc = (sk >> 16) & 63, yc = (sk >> 11) & 31;
+    bool in = (sk >> 31) && xc >= q.c0x && xc <= q.c1x && yc >= q.c0y && yc <= q.c1y;
+    int b0 = babs & 255, b1 = (babs >> 8) & 255, b2 = (babs >> 16) & 255, b3 = babs >> 24;
+    return in && b0 <= q.fx1 && b2 >= q.cx0 && b1 <= q.fy1 && b3 >= q.cy0;
+}
+
+// intersect_with_ray on a decoded candidate (entities.py:82-96,180-203)
+DEV double cand_toi(uint32_t s, double x1, double y1, double x2, double y2, double px, double py, double dx, double dy,
+                    double vel_sq, double radius) {
+    double t1, t2, t3;
+    if ((s & 1u) == 0) {
+        int wxu = (int)((s >> 6) & 3) - (int)((s >> 2) & 3), wyu = (int)((s >> 8) & 3) - (int)((s >> 4) & 3);
+        t1 = toi_circle_point(px, py, dx, dy, vel_sq, x1, y1, radius);
+        t2 = toi_circle_point(px, py, dx, dy, vel_sq, x2, y2, radius);
+        t3 = toi_circle_lineseg(px, py, dx, dy, x1, y1, wxu, wyu, radius);
+    } else {
+        double hor = ((s >> 6) & 1) ? 1.0 : -1.0, ver = ((s >> 7) & 1) ? 1.0 : -1.0;
+        t1 = toi_circle_point(px, py, dx, dy, vel_sq, x2, y1, radius);
+        t2 = toi_circle_point(px, py, dx, dy, vel_sq, x1, y2, radius);
+        t3 = toi_circle_arc(px, py, dx, dy, vel_sq, x1, y1, hor, ver, radius);
+    }
+    double t = t1;
+    if (t2 < t) t = t2;
+    if (t3 < t) t = t3;
+    return t;
+}
+
+// get_closest_point on a decoded candidate (entities.py:43-59,127-157)
+DEV bool cand_closest(uint32_t s, double x1, double y1, double x2, double y2, double px, double py, double &a, double &b) {
+    if ((s & 1u) == 0) {
+        int wxu = (int)((s >> 6) & 3) - (int)((s >> 2) & 3), wyu = (int)((s >> 8) & 3) - (int)((s >> 4) & 3);
+        double wx = 12.0 * wxu, wy = 12.0 * wyu;
+        double dx = px - x1, dy = py - y1;
+        int aw = wxu * wxu + wyu * wyu;
+        double num = dx * wx + dy * wy;
+        double u = aw == 1 ? div_const(num, 144.0, 1.0 / 144.0)
+                 : (aw == 8 ? div_const(num, 1152.0, 1.0 / 1152.0)
+                 : (aw == 5 ? div_const(num, 720.0, 1.0 / 720.0) : num / (sq(wx) + sq(wy))));
+        u = pymax(u, 0.0);
+        u = pymin(u, 1.0);
+        a = x1 + u * wx;
+        b = y1 + u * wy;
+        return dy * wx - dx * wy < 0;
+    }
+    double hor = ((s >> 6) & 1) ? 1.0 : -1.0, ver = ((s >> 7) & 1) ? 1.0 : -1.0;
+    bool convex = (s >> 8) & 1;
+    double dx = px - x1, dy = py - y1;
+    bool back = false;
+    if (dx * hor > 0 && dy * ver > 0) {
+        double dist = dsqrt(sq(dx) + sq(dy));
+        if (dist == 0) {
+            if (dx * hor > dy * ver) { a = x2; b = y1; }
+            else { a = x1; b = y2; }
+            return false;
+        }
+        a = x1 + 24.0 * dx / dist;
+        b = y1 + 24.0 * dy / dist;
+        back = convex ? (dist < 24.0) : (dist > 24.0);
+    } else {
+        if (dx * hor > dy * ver) { a = x2; b = y1; }
+        else { a = x1; b = y2; }
+    }
+    return back;
+}
+
+// sweep_circle_vs_tiles (physics.py:104-128).  The early `return 0` of the reference equals the minimum.
+template <int G>
+__device__ __noinline__ double sweep_generic(const Lv &lv, int r, double xo, double yo, double dx, double dy, double radius) {
     double xn = xo + dx, yn = yo + dy;
     double width = radius + 1;
     double qx0 = (xo < xn ? xo : xn) - width, qy0 = (yo < yn ? yo : yn) - width;
@@ -298,69 +549,115 @@ DEV double sweep_circle_vs_tiles(const Lv &lv, double xo, double yo, double dx, 
     int c0x = cell_coord(qx0, 43), c1x = cell_coord(qx1, 43), c0y = cell_coord(qy0, 24), c1y = cell_coord(qy1, 24);
     double vel_sq = sq(dx) + sq(dy);
     double shortest = 1;
-    for (int xc = c0x; xc <= c1x; xc++)
-        for (int yc = c0y; yc <= c1y; yc++) {
-            int c = xc * 25 + yc;
-            int s0 = lv.seg_start[c], s1 = lv.seg_start[c + 1];
-            if (s0 == s1) continue;
-            if (!cell_passes(lv, c, xc, yc, qx0, qy0, qx1, qy1)) continue;
-            for (int i = s0; i < s1; i++) {
-                double t = seg_toi(lv.segs[i], xc, yc, xo, yo, dx, dy, vel_sq, radius);
-                if (t == 0) return 0;
-                if (t < shortest) shortest = t;
-            }
+    for (int xc = c0x; xc <= c1x; xc++) {
+        int i0 = lv.seg_start[xc * 25 + c0y], i1 = lv.seg_start[xc * 25 + c1y + 1];   // the column's cells are contiguous
+        for (int i = i0 + r; i < i1; i += G) {
+            uint32_t s = lv.segs[i];
+            int yc = s >> 11;
+            if (!cell_passes(lv.bounds[xc * 25 + yc], xc, yc, qx0, qy0, qx1, qy1)) continue;
+            double t = seg_toi(s, xc, yc, xo, yo, dx, dy, vel_sq, radius);
+            if (t < shortest) shortest = t;
         }
-    return shortest;
+    }
+    return group_min<G>(shortest);
 }
 
-// Ninja.collide_vs_tiles (ninja.py:269-379)
-DEV void collide_vs_tiles(const Lv &lv, Nj &n, double xold, double yold, double &fnsx, double &fnsy, double &cnsx, double &cnsy) {
+// get_single_closest_point over the LDS tables (fallback of the register fast path)
+template <int G>
+__device__ __noinline__ void closest_generic(const Lv &lv, int r, const Query &qg, double gx0, double gy0, double gx1, double gy1,
+                                             double xpos, double ypos, Best &m) {
+    const double qx0 = xpos - NINJA_RADIUS, qy0 = ypos - NINJA_RADIUS, qx1 = xpos + NINJA_RADIUS, qy1 = ypos + NINJA_RADIUS;
+    int base = 0;
+    for (int xc = qg.c0x; xc <= qg.c1x; xc++) {
+        int i0 = lv.seg_start[xc * 25 + qg.c0y], i1 = lv.seg_start[xc * 25 + qg.c1y + 1];
+        for (int i = i0 + r; i < i1; i += G) {
+            uint32_t s = lv.segs[i];
+            int yc = s >> 11;
+            if (!cell_passes(lv.bounds[xc * 25 + yc], xc, yc, gx0, gy0, gx1, gy1)) continue;
+            double bx0, by0, bx1, by1;
+            seg_aabb(s, xc, yc, bx0, by0, bx1, by1);
+            if (bx1 < qx0 || bx0 > qx1 || by1 < qy0 || by0 > qy1) continue;
+            double a, b;
+            bool back = seg_closest(s, xc, yc, xpos, ypos, a, b);
+            double distance_sq = sq(xpos - a) + sq(ypos - b);
+            if (!back) distance_sq -= 0.1;
+            if (distance_sq < m.key) { m.key = distance_sq; m.a = a; m.b = b; m.idx = (base + i - i0) * 2 + (back ? 1 : 0); }
+        }
+        base += i1 - i0;
+    }
+}
+
+// Ninja.collide_vs_tiles (ninja.py:269-379).  Returns true when at least one depenetration was applied.
+template <int G, int K>
+DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double xold, double yold, double &fnsx, double &fnsy,
+                          double &cnsx, double &cnsy STAMP_ARG) {
     double dx = n.x - xold, dy = n.y - yold;
-    double time = sweep_circle_vs_tiles(lv, xold, yold, dx, dy, NINJA_RADIUS * 0.5);
+    // ---- sweep_circle_vs_tiles (physics.py:104-128); the early `return 0` of the reference equals the minimum
+    double time;
+    {
+        const double radius = NINJA_RADIUS * 0.5, width = radius + 1;
+        double xn = xold + dx, yn = yold + dy;
+        double qx0 = (xold < xn ? xold : xn) - width, qy0 = (yold < yn ? yold : yn) - width;
+        double qx1 = (xold > xn ? xold : xn) + width, qy1 = (yold > yn ? yold : yn) + width;
+        Query q = make_query(qx0, qy0, qx1, qy1);
+        if (cand_covers(cd, q)) {
+            double vel_sq = sq(dx) + sq(dy);
+            double shortest = 1;
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (cand_in_query(cd.s[k], cd.babs[k], q)) {
+                    double t = cand_toi(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], xold, yold, dx, dy, vel_sq, radius);
+                    if (t < shortest) shortest = t;
+                }
+            time = group_min<G>(shortest);
+        } else {
+            time = sweep_generic<G>(lv, r, xold, yold, dx, dy, radius);
+        }
+    }
     n.x = xold + time * dx;
     n.y = yold + time * dy;
-    // the segment list is gathered ONCE at the post-sweep position (ninja.py:282-285): remember which cells passed
-    double gx0 = n.x - NINJA_RADIUS, gy0 = n.y - NINJA_RADIUS, gx1 = n.x + NINJA_RADIUS, gy1 = n.y + NINJA_RADIUS;
-    int c0x = cell_coord(gx0, 43), c1x = cell_coord(gx1, 43), c0y = cell_coord(gy0, 24), c1y = cell_coord(gy1, 24);
-    uint32_t cmask = 0;
-    for (int xc = c0x; xc <= c1x; xc++)
-        for (int yc = c0y; yc <= c1y; yc++) {
-            int c = xc * 25 + yc;
-            if (lv.seg_start[c] == lv.seg_start[c + 1]) continue;
-            if (cell_passes(lv, c, xc, yc, gx0, gy0, gx1, gy1)) cmask |= 1u << ((xc - c0x) * 4 + (yc - c0y));
-        }
-    if (cmask == 0) return;
+    // the segment list is gathered ONCE at the post-sweep position (ninja.py:282-285): the cell filter keeps using
+    // this box for all iterations, the per-segment AABB test uses the moving position (physics.py:150-167)
+    const double gx0 = n.x - NINJA_RADIUS, gy0 = n.y - NINJA_RADIUS, gx1 = n.x + NINJA_RADIUS, gy1 = n.y + NINJA_RADIUS;
+    const Query qg = make_query(gx0, gy0, gx1, gy1);
+    const bool fast = cand_covers(cd, qg);
+    uint32_t gp = 0;
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < K; k++) gp |= cand_in_query(cd.s[k], cd.babs[k], qg) ? (1u << k) : 0u;
+    }
     double xpos = n.x, ypos = n.y, xspeed = n.vx, yspeed = n.vy;
+    bool applied = false;
+    STAMP(9);   // sweep + gather setup
     for (int it = 0; it < 32; it++) {
+#ifdef NPP_STAMPS
+        st.acc[fast ? 10 : 11] += 1;   // iteration counts (fast / LDS fallback)
+#endif
         // get_single_closest_point (physics.py:131-180)
-        double shortest = __builtin_inf();
-        int result = 0;
-        double ca = 0, cb = 0;
-        double qx0 = xpos - NINJA_RADIUS, qy0 = ypos - NINJA_RADIUS, qx1 = xpos + NINJA_RADIUS, qy1 = ypos + NINJA_RADIUS;
-        for (int xc = c0x; xc <= c1x; xc++)
-            for (int yc = c0y; yc <= c1y; yc++) {
-                if (!((cmask >> ((xc - c0x) * 4 + (yc - c0y))) & 1u)) continue;
-                int c = xc * 25 + yc;
-                int s0 = lv.seg_start[c], s1 = lv.seg_start[c + 1];
-                for (int i = s0; i < s1; i++) {
-                    uint32_t s = lv.segs[i];
-                    double bx0, by0, bx1, by1;
-                    seg_aabb(s, xc, yc, bx0, by0, bx1, by1);
+        Best m;
+        m.key = __builtin_inf(); m.idx = 0x7fffffff; m.a = 0; m.b = 0;
+        const double qx0 = xpos - NINJA_RADIUS, qy0 = ypos - NINJA_RADIUS, qx1 = xpos + NINJA_RADIUS, qy1 = ypos + NINJA_RADIUS;
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if ((gp >> k) & 1u) {
+                    double bx0 = cd.x1[k] < cd.x2[k] ? cd.x1[k] : cd.x2[k], bx1 = cd.x1[k] < cd.x2[k] ? cd.x2[k] : cd.x1[k];
+                    double by0 = cd.y1[k] < cd.y2[k] ? cd.y1[k] : cd.y2[k], by1 = cd.y1[k] < cd.y2[k] ? cd.y2[k] : cd.y1[k];
                     if (bx1 < qx0 || bx0 > qx1 || by1 < qy0 || by0 > qy1) continue;
                     double a, b;
-                    bool back = seg_closest(s, xc, yc, xpos, ypos, a, b);
+                    bool back = cand_closest(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], xpos, ypos, a, b);
                     double distance_sq = sq(xpos - a) + sq(ypos - b);
                     if (!back) distance_sq -= 0.1;
-                    if (distance_sq < shortest) {
-                        shortest = distance_sq;
-                        ca = a; cb = b;
-                        result = back ? -1 : 1;
-                    }
+                    if (distance_sq < m.key) { m.key = distance_sq; m.a = a; m.b = b; m.idx = (k * G + r) * 2 + (back ? 1 : 0); }
                 }
-            }
-        if (result == 0) break;
-        dx = xpos - ca;
-        dy = ypos - cb;
+        } else {
+            closest_generic<G>(lv, r, qg, gx0, gy0, gx1, gy1, xpos, ypos, m);
+        }
+        group_argmin<G>(m);
+        if (m.idx == 0x7fffffff) break;   // result == 0
+        const int result = (m.idx & 1) ? -1 : 1;
+        dx = xpos - m.a;
+        dy = ypos - m.b;
         if (dabs(dx) <= 0.0000001) {   // band-aid constants of the reference (ninja.py:313-318)
             dx = 0;
             if (xpos == 50.51197510492316 || xpos == 49.23232124849253) dx = -0x1p-47;
@@ -371,6 +668,7 @@ DEV void collide_vs_tiles(const Lv &lv, Nj &n, double xold, double yold, double 
         double dist = dsqrt(dist_sq);
         double depen_len = NINJA_RADIUS - dist * result;
         if (depen_len < 0.0000001) break;
+        applied = true;
         double inv_dist = 1.0 / dist;
         double norm_dx = dx * inv_dist, norm_dy = dy * inv_dist;
         xpos += norm_dx * depen_len;
@@ -386,6 +684,7 @@ DEV void collide_vs_tiles(const Lv &lv, Nj &n, double xold, double yold, double 
         else { n.fcount += 1; fnsx += norm_dx; fnsy += norm_dy; }
     }
     n.x = xpos; n.y = ypos; n.vx = xspeed; n.vy = yspeed;
+    return applied;
 }
 
 // overlap_circle_vs_circle (physics.py:204-207) with an exact-safe early reject
@@ -407,8 +706,8 @@ DEV double mine_radius(uint32_t st) { return st == 0 ? 4.0 : (st == 1 ? 3.5 : 4.
 // EntityToggleMine.think for every mine that can change (entity_toggle_mine.py:90-118).  The reference visits all
 // mines each tick; only mines within one cell of the ninja now or at the previous think can change state
 // (overlap radius <= 14.5 px < 24 px), and visiting a superset is harmless, so the bounding box of the two 3x3
-// neighbourhoods is scanned.
-DEV void think_mines(const Lv &lv, Nj &n, uint32_t *ew, int lane) {
+// neighbourhoods is scanned.  (All lanes of a group run this redundantly and write identical LDS words.)
+DEV void think_mines(const Lv &lv, Nj &n, EntBits eb) {
     int ccx = cell_coord(n.x, 43), ccy = cell_coord(n.y, 24);
     int pcx = n.pcell / 25, pcy = n.pcell - pcx * 25;
     n.pcell = ccx * 25 + ccy;
@@ -422,12 +721,12 @@ DEV void think_mines(const Lv &lv, Nj &n, uint32_t *ew, int lane) {
         int i0 = lv.ent_start[xc * 25 + y0], i1 = lv.ent_start[xc * 25 + y1 + 1];
         for (int i = i0; i < i1; i++) {
             if ((lv.ent_meta[i] & 15u) != EK_MINE) continue;
-            uint32_t st = ent_get(ew, lane, i);
+            uint32_t st = ent_get(eb, i);
             if (vt) {
-                if (st == 1) { if (overlaps(lv.ent_x[i], lv.ent_y[i], 3.5 + NINJA_RADIUS, n.x, n.y)) ent_set(ew, lane, i, 2); }
-                else if (st == 2) { if (!overlaps(lv.ent_x[i], lv.ent_y[i], 4.5 + NINJA_RADIUS, n.x, n.y)) ent_set(ew, lane, i, 0); }
+                if (st == 1) { if (overlaps(lv.ent_x[i], lv.ent_y[i], 3.5 + NINJA_RADIUS, n.x, n.y)) ent_set(eb, i, 2); }
+                else if (st == 2) { if (!overlaps(lv.ent_x[i], lv.ent_y[i], 4.5 + NINJA_RADIUS, n.x, n.y)) ent_set(eb, i, 0); }
             } else if (st == 2) {
-                ent_set(ew, lane, i, 1);
+                ent_set(eb, i, 1);
             }
         }
     }
@@ -435,7 +734,7 @@ DEV void think_mines(const Lv &lv, Nj &n, uint32_t *ew, int lane) {
 
 // logical collisions of post_collision (ninja.py:388-420) over the 3x3 neighbourhood gathered x-major
 // (physics.py:79-101); an exit door added to the grid by its switch this tick is not in the snapshot.
-DEV void logical_collisions(const Lv &lv, Nj &n, uint32_t *ew, int lane) {
+DEV void logical_collisions(const Lv &lv, Nj &n, EntBits eb) {
     int cx = cell_coord(n.x, 43), cy = cell_coord(n.y, 24);
     int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < 43 ? cx + 1 : 43, y0 = cy > 0 ? cy - 1 : 0, y1 = cy < 24 ? cy + 1 : 24;
     int pend0 = -1, pend1 = -1;
@@ -444,58 +743,107 @@ DEV void logical_collisions(const Lv &lv, Nj &n, uint32_t *ew, int lane) {
         for (int i = i0; i < i1; i++) {
             uint32_t meta = lv.ent_meta[i];
             uint32_t kind = meta & 15u;
-            uint32_t st = ent_get(ew, lane, i);
+            uint32_t st = ent_get(eb, i);
             double ex = lv.ent_x[i], ey = lv.ent_y[i];
             if (kind == EK_MINE) {   // entity_toggle_mine.py:120-128
                 if (valid_target(n.state) && st == 0 && overlaps(ex, ey, 4.0 + NINJA_RADIUS, n.x, n.y)) {
-                    ent_set(ew, lane, i, 1);
+                    ent_set(eb, i, 1);
                     ninja_kill(n, 1);
                 }
             } else if (st == 0) {
                 continue;   // inactive (or exit door not yet in the grid)
             } else if (kind == EK_GOLD) {   // entity_gold.py:66-74
-                if (n.state != 8 && overlaps(ex, ey, 6.0 + NINJA_RADIUS, n.x, n.y)) { n.gold += 1; ent_set(ew, lane, i, 0); }
+                if (n.state != 8 && overlaps(ex, ey, 6.0 + NINJA_RADIUS, n.x, n.y)) { n.gold += 1; ent_set(eb, i, 0); }
             } else if (kind == EK_EXIT) {   // entity_exit.py:66-74
                 if (overlaps(ex, ey, 12.0 + NINJA_RADIUS, n.x, n.y)) ninja_win(n);
             } else if (kind == EK_SWITCH) { // entity_exit_switch.py:67-129
                 if (overlaps(ex, ey, 6.0 + NINJA_RADIUS, n.x, n.y)) {
-                    ent_set(ew, lane, i, 0);
+                    ent_set(eb, i, 0);
                     int door = (int)((meta >> 8) & 0xffffu);
                     if (pend0 < 0) pend0 = door; else pend1 = door;
                 }
             } else if (kind == EK_LOCKED) { // entity_door_locked.py:54-67
-                if (overlaps(ex, ey, 5.0 + NINJA_RADIUS, n.x, n.y)) { n.doors += 1; ent_set(ew, lane, i, 0); }
+                if (overlaps(ex, ey, 5.0 + NINJA_RADIUS, n.x, n.y)) { n.doors += 1; ent_set(eb, i, 0); }
             }
         }
     }
-    if (pend0 >= 0) ent_set(ew, lane, pend0, 1);
-    if (pend1 >= 0) ent_set(ew, lane, pend1, 1);
+    if (pend0 >= 0) ent_set(eb, pend0, 1);
+    if (pend1 >= 0) ent_set(eb, pend1, 1);
+}
+
+// sum the wall-probe terms of one pass in lane (= query) order (ninja.py:441)
+template <int G> DEV void ordered_add(double &acc, double term) {
+    if constexpr (G == 1) {
+        acc += term;
+    } else {
+        const int glane0 = (threadIdx.x & 63) & ~(G - 1);
+        unsigned long long bal = __ballot(term != 0) >> glane0;
+        if constexpr (G < 64) bal &= (1ull << G) - 1;
+        while (bal) {
+            int k = __builtin_ctzll(bal);
+            bal &= bal - 1;
+            acc += __shfl(term, glane0 + k, 64);
+        }
+    }
+}
+
+DEV double wall_term(double px, double py, double a, double b, double rad) {
+    double dx = px - a, dy = py - b;
+    if (dabs(dy) < 0.00001) {
+        double dist = dsqrt(sq(dx) + sq(dy));
+        if (0 < dist && dist <= rad) return dx / dist;
+    }
+    return 0;
+}
+
+template <int G>
+__device__ __noinline__ double wall_probe_generic(const Lv &lv, int r, const Query &q, double px, double py, double qx0, double qy0,
+                                                  double qx1, double qy1) {
+    const double rad = NINJA_RADIUS + 0.1;
+    double wall_normal = 0;
+    for (int xc = q.c0x; xc <= q.c1x; xc++) {
+        int i0 = lv.seg_start[xc * 25 + q.c0y], i1 = lv.seg_start[xc * 25 + q.c1y + 1];
+        for (int ib = i0; ib < i1; ib += G) {   // group-uniform trip count
+            int i = ib + r;
+            double term = 0;
+            if (i < i1) {
+                uint32_t s = lv.segs[i];
+                int yc = s >> 11;
+                if (cell_passes(lv.bounds[xc * 25 + yc], xc, yc, qx0, qy0, qx1, qy1)) {
+                    double a, b;
+                    seg_closest(s, xc, yc, px, py, a, b);
+                    term = wall_term(px, py, a, b, rad);
+                }
+            }
+            ordered_add<G>(wall_normal, term);
+        }
+    }
+    return wall_normal;
 }
 
 // Ninja.post_collision (ninja.py:381-537)
-DEV void post_collision(const Lv &lv, Nj &n, uint32_t *ew, int lane, double fnsx, double fnsy, double cnsx, double cnsy) {
-    logical_collisions(lv, n, ew, lane);
-    // wall probe (ninja.py:424-441)
+template <int G, int K>
+DEV void post_collision(const Lv &lv, int r, Nj &n, const Cand<K> &cd, EntBits eb, double fnsx, double fnsy, double cnsx, double cnsy) {
+    logical_collisions(lv, n, eb);
+    // wall probe (ninja.py:424-441): terms summed in query order
     double wall_normal = 0;
     const double rad = NINJA_RADIUS + 0.1;
     double qx0 = n.x - rad, qy0 = n.y - rad, qx1 = n.x + rad, qy1 = n.y + rad;
-    int c0x = cell_coord(qx0, 43), c1x = cell_coord(qx1, 43), c0y = cell_coord(qy0, 24), c1y = cell_coord(qy1, 24);
-    for (int xc = c0x; xc <= c1x; xc++)
-        for (int yc = c0y; yc <= c1y; yc++) {
-            int c = xc * 25 + yc;
-            int s0 = lv.seg_start[c], s1 = lv.seg_start[c + 1];
-            if (s0 == s1) continue;
-            if (!cell_passes(lv, c, xc, yc, qx0, qy0, qx1, qy1)) continue;
-            for (int i = s0; i < s1; i++) {
+    const Query q = make_query(qx0, qy0, qx1, qy1);
+    if (cand_covers(cd, q)) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            double term = 0;
+            if (cand_in_query(cd.s[k], cd.babs[k], q)) {
                 double a, b;
-                seg_closest(lv.segs[i], xc, yc, n.x, n.y, a, b);
-                double dx = n.x - a, dy = n.y - b;
-                if (dabs(dy) < 0.00001) {
-                    double dist = dsqrt(sq(dx) + sq(dy));
-                    if (0 < dist && dist <= rad) wall_normal += dx / dist;
-                }
+                cand_closest(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], n.x, n.y, a, b);
+                term = wall_term(n.x, n.y, a, b, rad);
             }
+            ordered_add<G>(wall_normal, term);
         }
+    } else {
+        wall_normal = wall_probe_generic<G>(lv, r, q, n.x, n.y, qx0, qy0, qx1, qy1);
+    }
     n.airborn_old = n.airborn;
     n.airborn = 1;
     n.walled = 0;
@@ -655,11 +1003,15 @@ DEV void ninja_think(Nj &n) {
 }
 
 // Simulator.tick (nsim.py:221-292)
-DEV void sim_tick(const Lv &lv, Nj &n, uint32_t *ew, int lane, int hor, int jump) {
+template <int G>
+DEV void sim_tick(const Lv &lv, int r, Nj &n, EntBits eb, int hor, int jump STAMP_ARG) {
+    constexpr int K = KSlots<G>::value;
+    STAMP_INIT;
     n.frame += 1;
     n.hor = hor;
     n.jump = jump;
-    think_mines(lv, n, ew, lane);
+    think_mines(lv, n, eb);
+    STAMP(2);
     if (n.state == 9) return;
     if (n.state != 6) {
         // integrate (ninja.py:198-206)
@@ -674,16 +1026,34 @@ DEV void sim_tick(const Lv &lv, Nj &n, uint32_t *ew, int lane, int hor, int jump
         n.vxo = n.vx; n.vyo = n.vy;
         n.fcount = 0; n.ccount = 0;
         double fnsx = 0, fnsy = 0, cnsx = 0, cnsy = 0;
-        // 4 substeps (nsim.py:263-267); collide_vs_objects has nothing physical to hit on this path
-        for (int k = 0; k < 4; k++) collide_vs_tiles(lv, n, xold, yold, fnsx, fnsy, cnsx, cnsy);
-        post_collision(lv, n, ew, lane, fnsx, fnsy, cnsx, cnsy);
+        // candidate segments for every query of this tick: cells touched by the path inflated by the largest
+        // query radius (10.1) plus slack for depenetration drift
+        Cand<K> cd;
+        {
+            const double pad = NINJA_RADIUS + 2.2;
+            cand_gather<G, K>(lv, r, (xold < n.x ? xold : n.x) - pad, (yold < n.y ? yold : n.y) - pad,
+                              (xold > n.x ? xold : n.x) + pad, (yold > n.y ? yold : n.y) + pad, cd);
+        }
+        STAMP(3);
+        // 4 substeps (nsim.py:263-267); collide_vs_objects has nothing physical to hit on this path.  A substep
+        // that applies no depenetration and leaves the position bit-identical has the same inputs as the next
+        // one, so the remaining substeps are no-ops and are skipped.
+        for (int k = 0; k < 4; k++) {
+            const double xb = n.x, yb = n.y;
+            bool applied = collide_vs_tiles<G, K>(lv, r, n, cd, xold, yold, fnsx, fnsy, cnsx, cnsy STAMP_PASS);
+            if (!applied && n.x == xb && n.y == yb) break;
+        }
+        STAMP(4);
+        post_collision<G, K>(lv, r, n, cd, eb, fnsx, fnsy, cnsx, cnsy);
+        STAMP(5);
     }
     ninja_think(n);
+    STAMP(6);
 }
 
 // ---- observations ---------------------------------------------------------------------------------------------
 // get_ninja_state (nplay_headless.py:735-924) + time_remaining (base_environment.py:2811-2829); fp64 then f32 cast
-DEV void write_game_state(const Nj &n, int limit, float *o /* stride 1 */) {
+__device__ __noinline__ void write_game_state(const Nj &n, int limit, float *o /* stride 1 */) {
     double vmag = dsqrt(sq(n.vx) + sq(n.vy));
     o[0] = (float)(pymin(vmag / (MAX_HOR_SPEED * 2), 1.0) * 2 - 1);
     bool mv = vmag > 1e-6;
@@ -748,34 +1118,44 @@ DEV uint32_t action_mask_bits(const Nj &n) {
     return mask;
 }
 
-// contiguous wave store of per-lane rows of `width` 4-byte words staged at stage[lane * width + k]
-DEV void wave_store_rows(const uint32_t *stage, uint32_t *dst_block, int width, int lane, int n_valid) {
+// contiguous workgroup store of per-env rows of `width` 4-byte words staged at stage[env_in_block * width + k]
+DEV void block_store_rows(const uint32_t *stage, uint32_t *dst_block, int width, int n_valid) {
     int total = n_valid * width;
-    for (int j = lane; j < total; j += BLOCK) dst_block[j] = stage[j];
+    for (int j = threadIdx.x; j < total; j += blockDim.x) dst_block[j] = stage[j];
 }
 
-template <bool LDS_LEVEL>
+// G lanes per env; EPW = 64 / G envs per wavefront; blockDim.x / 64 wavefronts per workgroup
+template <int G, bool LDS_LEVEL>
 DEV void run(const KernelArgs &a, unsigned char *smem) {
-    const int lane = threadIdx.x;
-    const int env0 = blockIdx.x * BLOCK;
-    const int env = env0 + lane;
+    constexpr int EPW = WAVE / G;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int r = lane & (G - 1);          // rank inside the env's lane group
+    const int epb = EPW * (blockDim.x >> 6);   // envs per workgroup
+    const int eib = wave * EPW + lane / G;     // env index inside the workgroup
+    const int env0 = blockIdx.x * epb;
+    const int env = env0 + eib;
     const bool valid = env < a.n;
     const int e = valid ? env : a.n - 1;
-    const int n_valid = (a.n - env0) < BLOCK ? (a.n - env0) : BLOCK;
+    const int n_valid = (a.n - env0) < epb ? (a.n - env0) : epb;
 
-    uint32_t *ew = reinterpret_cast<uint32_t *>(smem + a.lds_hot_cap);
-    uint32_t *stage = ew + (size_t)a.n_words_max * BLOCK;
+    uint32_t *ew = reinterpret_cast<uint32_t *>(smem + (LDS_LEVEL ? a.lds_hot_cap : 0u));
+    uint32_t *stage = ew + (size_t)a.n_words_max * epb;
+    EntBits eb;
+    eb.w = ew + eib;
+    eb.stride = epb;
 
     const int lvl = a.env_level[e];
     const LevelHdr &H = a.hdr[lvl];
     Lv lv;
     const unsigned char *hot = a.blob + H.off_hot;
     if (LDS_LEVEL) {
-        // all 64 envs of this workgroup play level `lvl`: stage its collision table into LDS with 16-byte loads
+        // every env of this workgroup plays level `lvl`: stage its collision table into LDS with 16-byte loads
         const uint4 *src = reinterpret_cast<const uint4 *>(hot);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const int nvec = (int)(H.hot_bytes >> 4);
-        for (int i = lane; i < nvec; i += BLOCK) dst[i] = src[i];
+        for (int i = tid; i < nvec; i += blockDim.x) dst[i] = src[i];
         hot = smem;
     }
     lv.seg_start = reinterpret_cast<const uint16_t *>(hot + HOT_SEG_START);
@@ -791,45 +1171,52 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     lv.spawn_x = H.spawn_x; lv.spawn_y = H.spawn_y;
     lv.sw_x = H.sw_x; lv.sw_y = H.sw_y; lv.door_x = H.door_x; lv.door_y = H.door_y;
 
+#ifdef NPP_STAMPS
+    Stamps st;
+    for (int i = 0; i < N_STAMP; i++) st.acc[i] = 0;
+#endif
+    STAMP_INIT;
     Nj n;
     load_state(a, e, n);
     const int nw = (int)lv.n_words;
-    for (int w = 0; w < nw; w++) ew[w * BLOCK + lane] = a.ent_bits[(size_t)w * a.n + e];
+    if (r == 0)
+        for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = a.ent_bits[(size_t)w * a.n + e];
     __syncthreads();
 
+    STAMP(0);
     const int limit = a.trunc_limit[e];
     uint32_t flags = 0;
     int executed = 0;
     float reward = 0.f;
-    const bool had_switch = lv.obs_switch >= 0 && ent_get(ew, lane, lv.obs_switch) == 0;
+    const bool had_switch = lv.obs_switch >= 0 && ent_get(eb, lv.obs_switch) == 0;
 
-    if (a.mode == 0) {
-        // NppEnvironment.step frame-skip loop (base_environment.py:524-609)
-        const int act = a.n_ticks > 0 ? a.inputs[e] : 0;
-        const int hor = (act == 1 || act == 4) ? -1 : ((act == 2 || act == 5) ? 1 : 0);   // :366-402
-        const int jump = act >= 3 ? 1 : 0;
-        // an env that is already terminal (no auto-reset) is not stepped again until the caller resets it
-        bool live = valid && !(n.state == 8 || n.state == 6 || n.state == 7);
+    {
+        // mode 0: NppEnvironment.step frame-skip loop (base_environment.py:524-609), action table :366-402; an env that
+        //         is already terminal (no auto-reset) is not stepped again until the caller resets it
+        // mode 1: NPlayHeadless.tick driven by replay bytes (replay/replay_executor.py:61-84), never stops early
+        const bool gym = a.mode == 0;
+        const int act = (gym && a.n_ticks > 0) ? a.inputs[e] : 0;
+        int hor = (act == 1 || act == 4) ? -1 : ((act == 2 || act == 5) ? 1 : 0);
+        int jump = act >= 3 ? 1 : 0;
+        bool live = valid && !(gym && (n.state == 8 || n.state == 6 || n.state == 7));
         for (int t = 0; t < a.n_ticks; t++) {
+            if (!gym) {
+                const int b = a.inputs[(size_t)t * a.n + e];
+                const int l = (b >> 2) & 1, rr = (b >> 1) & 1;
+                hor = (l && rr) ? 0 : (l ? -1 : (rr ? 1 : 0));
+                jump = b & 1;
+            }
             if (live) {
-                sim_tick(lv, n, ew, lane, hor, jump);
+                sim_tick<G>(lv, r, n, eb, hor, jump STAMP_PASS);
                 executed++;
-                if (n.state == 8 || n.state == 6 || n.state == 7) live = false;
+                if (gym && (n.state == 8 || n.state == 6 || n.state == 7)) live = false;
             }
             if (!__any(live)) break;
         }
-    } else {
-        // NPlayHeadless.tick driven by replay bytes (replay/replay_executor.py:61-84)
-        for (int t = 0; t < a.n_ticks; t++) {
-            const int b = a.inputs[(size_t)t * a.n + e];
-            const int l = (b >> 2) & 1, r = (b >> 1) & 1;
-            const int hor = (l && r) ? 0 : (l ? -1 : (r ? 1 : 0));
-            if (valid) sim_tick(lv, n, ew, lane, hor, b & 1);
-            executed++;
-        }
     }
 
-    const bool sw_now = lv.obs_switch >= 0 ? ent_get(ew, lane, lv.obs_switch) == 0 : true;   // nplay_headless.py:566-576
+    STAMP(1);
+    const bool sw_now = lv.obs_switch >= 0 ? ent_get(eb, lv.obs_switch) == 0 : true;   // nplay_headless.py:566-576
     if (n.state == 8) flags |= 1u;
     if (n.state == 6 || n.state == 7) flags |= 2u;
     if (sw_now) flags |= 4u;
@@ -843,62 +1230,70 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     if (flags & 2u) reward -= 3.f;
     if (sw_now && !had_switch && lv.obs_switch >= 0) reward += 10.f;
 
-    if (valid) {
+    const bool writer = valid && r == 0;
+    if (writer) {
         if (a.out.flags) a.out.flags[env] = (uint8_t)flags;
         if (a.out.reward) a.out.reward[env] = reward;
         if (a.out.frames) a.out.frames[env] = (uint16_t)executed;
     }
 
     const bool do_reset = a.autoreset && stepping && done;
-    if (a.out.terminal_state && do_reset && valid) write_game_state(n, limit, a.out.terminal_state + (size_t)env * 41);
+    if (a.out.terminal_state && do_reset && writer) write_game_state(n, limit, a.out.terminal_state + (size_t)env * 41);
     if (do_reset) {
         spawn_state(lv, n);
-        for (int w = 0; w < nw; w++) ew[w * BLOCK + lane] = lv.init_words[w];
+        for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
     }
 
-    // observations, assembled in LDS then stored as contiguous wave writes
+    // observations, assembled in LDS then stored as contiguous workgroup writes
     if (a.out.game_state) {
-        float *row = reinterpret_cast<float *>(stage) + lane * 41;
-        write_game_state(n, limit, row);
+        if (r == 0) write_game_state(n, limit, reinterpret_cast<float *>(stage) + eib * 41);
         __syncthreads();
-        wave_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.game_state + (size_t)env0 * 41), 41, lane, n_valid);
+        block_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.game_state + (size_t)env0 * 41), 41, n_valid);
         __syncthreads();
     }
     if (a.out.entity_pos) {
-        float *row = reinterpret_cast<float *>(stage) + lane * 6;
-        row[0] = (float)(n.x / 1056.0); row[1] = (float)(n.y / 600.0);
-        row[2] = (float)(lv.sw_x / 1056.0); row[3] = (float)(lv.sw_y / 600.0);
-        row[4] = (float)(lv.door_x / 1056.0); row[5] = (float)(lv.door_y / 600.0);
+        if (r == 0) {
+            float *row = reinterpret_cast<float *>(stage) + eib * 6;
+            row[0] = (float)(n.x / 1056.0); row[1] = (float)(n.y / 600.0);
+            row[2] = (float)(lv.sw_x / 1056.0); row[3] = (float)(lv.sw_y / 600.0);
+            row[4] = (float)(lv.door_x / 1056.0); row[5] = (float)(lv.door_y / 600.0);
+        }
         __syncthreads();
-        wave_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.entity_pos + (size_t)env0 * 6), 6, lane, n_valid);
+        block_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.entity_pos + (size_t)env0 * 6), 6, n_valid);
         __syncthreads();
     }
-    if (a.out.action_mask && valid) {
+    if (a.out.action_mask && writer) {
         uint32_t m = action_mask_bits(n);
         int8_t *row = a.out.action_mask + (size_t)env * 6;
         for (int k = 0; k < 6; k++) row[k] = (int8_t)((m >> k) & 1u);
     }
 
-    if (valid) {
+    STAMP(7);
+    if (writer) {
         store_state(a, env, n);
-        for (int w = 0; w < nw; w++) a.ent_bits[(size_t)w * a.n + env] = ew[w * BLOCK + lane];
+        for (int w = 0; w < nw; w++) a.ent_bits[(size_t)w * a.n + env] = eb.w[w * eb.stride];
     }
+    STAMP(8);
+#ifdef NPP_STAMPS
+    if (lane == 0) {
+        unsigned gw = blockIdx.x * (blockDim.x >> 6) + wave;
+        if (gw < 16384)
+            for (int i = 0; i < N_STAMP; i++) g_stamps[gw * N_STAMP + i] += st.acc[i];
+    }
+#endif
 }
 
-__global__ __launch_bounds__(BLOCK) void npp_step_kernel(KernelArgs a) {
+// LDS_LEVEL is chosen by the host: true when every workgroup's envs play one level that fits the LDS budget
+// (the host knows the env -> level assignment), false otherwise (tables are read through L1/L2).
+template <int G, bool LDS_LEVEL>
+__global__ __launch_bounds__(256) void npp_step_kernel(KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int env = blockIdx.x * BLOCK + threadIdx.x;
-    const int e = env < a.n ? env : a.n - 1;
-    const int lvl = a.env_level[e];
-    const int lvl0 = __builtin_amdgcn_readfirstlane(lvl);
-    const bool uniform = __all(lvl == lvl0) && a.hdr[lvl0].fits_lds;
-    if (uniform) run<true>(a, smem);
-    else run<false>(a, smem);
+    run<G, LDS_LEVEL>(a, smem);
 }
 
 // Simulator.reset / fast_reset (nsim.py:62-140) for masked envs
-__global__ __launch_bounds__(BLOCK) void npp_reset_kernel(KernelArgs a) {
-    const int env = blockIdx.x * BLOCK + threadIdx.x;
+__global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= a.n) return;
     if (a.reset_mask && a.reset_mask[env] == 0) return;
     const LevelHdr &H = a.hdr[a.env_level[env]];
@@ -911,21 +1306,67 @@ __global__ __launch_bounds__(BLOCK) void npp_reset_kernel(KernelArgs a) {
     for (uint32_t w = 0; w < H.n_words; w++) a.ent_bits[(size_t)w * a.n + env] = init[w];
 }
 
-}  // namespace
-
-hipError_t launch_step(const KernelArgs &a, hipStream_t s) {
-    const int blocks = (a.n + BLOCK - 1) / BLOCK;
-    const size_t lds = lds_bytes(a.lds_hot_cap, a.n_words_max);
-    hipLaunchKernelGGL(npp_step_kernel, dim3(blocks), dim3(BLOCK), lds, s, a);
+template <int G>
+hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
+    const int wpb = a.waves_per_block;
+    const int epb = (WAVE / G) * wpb;
+    const int blocks = (a.n + epb - 1) / epb;
+    const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb);
+    if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
+    else hipLaunchKernelGGL((npp_step_kernel<G, false>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
     return hipGetLastError();
 }
 
+}  // namespace
+
+hipError_t launch_step(const KernelArgs &a, hipStream_t s) {
+    switch (a.lanes_per_env) {
+        case 1: return launch_step_g<1>(a, s);
+        case 2: return launch_step_g<2>(a, s);
+        case 4: return launch_step_g<4>(a, s);
+        case 8: return launch_step_g<8>(a, s);
+        case 16: return launch_step_g<16>(a, s);
+        case 32: return launch_step_g<32>(a, s);
+        case 64: return launch_step_g<64>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_reset(const KernelArgs &a, hipStream_t s) {
-    const int blocks = (a.n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(npp_reset_kernel, dim3(blocks), dim3(BLOCK), 0, s, a);
+    const int blocks = (a.n + 63) / 64;
+    hipLaunchKernelGGL(npp_reset_kernel, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_render(const KernelArgs &, uint8_t *, hipStream_t) { return hipErrorNotSupported; }
+
+#ifdef NPP_STAMPS
+extern "C" int npp_debug_stamps(unsigned long long *out, int n_waves, int reset) {
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)N_STAMP * 16384);
+    hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * h.size());
+    if (out) {
+        for (int i = 0; i < N_STAMP; i++) out[i] = 0;
+        for (int w = 0; w < n_waves && w < 16384; w++)
+            for (int i = 0; i < N_STAMP; i++) out[i] += h[(size_t)w * N_STAMP + i];
+        // per-wave totals (all phases) -> out[N_STAMP .. N_STAMP + n_waves)
+        for (int w = 0; w < n_waves && w < 16384; w++) {
+            unsigned long long t = 0;
+            for (int i = 0; i < N_STAMP; i++) t += h[(size_t)w * N_STAMP + i];
+            out[N_STAMP + w] = t;
+        }
+        // breakdown of the slowest wave after the totals
+        int wmax = 0;
+        for (int w = 1; w < n_waves && w < 16384; w++)
+            if (out[N_STAMP + w] > out[N_STAMP + wmax]) wmax = w;
+        for (int i = 0; i < N_STAMP; i++) out[N_STAMP + n_waves + i] = h[(size_t)wmax * N_STAMP + i];
+    }
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0ull);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h.data(), sizeof(unsigned long long) * h.size());
+    }
+    return 0;
+}
+#endif
 
 }  // namespace npp

@@ -158,7 +158,7 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
             }
             bx0 = std::min(bx0, x0); by0 = std::min(by0, y0);
             bx1 = std::max(bx1, x1); by1 = std::max(by1, y1);
-            L.segs.push_back(s);
+            L.segs.push_back((uint16_t)(s | (uint16_t)((c % GRID_H) << 11)));   // bits 11-15: the owning cell's y
         }
         if (!cell[c].empty()) L.cell_bounds[c] = (uint8_t)(bx0 | (by0 << 2) | (bx1 << 4) | (by1 << 6));
     }

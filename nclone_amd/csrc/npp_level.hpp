@@ -22,6 +22,7 @@ enum EntKind : uint32_t { EK_NONE = 0, EK_MINE = 1, EK_GOLD = 2, EK_EXIT = 3, EK
 // Packed collision segment (uint16), coordinates in units of 12 px relative to the owning cell's origin:
 //   linear : bit0 = 0, bits 2-3 x1, 4-5 y1, 6-7 x2, 8-9 y2
 //   arc    : bit0 = 1, bits 2-3 cx, 4-5 cy, bit6 hor>0, bit7 ver>0, bit8 convex
+//   both   : bits 11-15 = y of the owning cell (a query walks whole cell columns, which are contiguous in the CSR)
 // Packed cell bounds (uint8): bits 0-1 min x, 2-3 min y, 4-5 max x, 6-7 max y (same units).
 struct CompiledLevel {
     std::vector<uint16_t> seg_start;   // [N_CELLS+1] CSR over cells

@@ -95,6 +95,14 @@ class NppBatch:
             assert len(lim) == self.n
             nat.check(self.h, self.lib.npp_set_truncation_limit(self.h, lim.ctypes.data_as(C.POINTER(C.c_int32)), 0))
 
+    def set_launch_geometry(self, lanes_per_env=0, waves_per_block=0):
+        nat.check(self.h, self.lib.npp_set_launch_geometry(self.h, int(lanes_per_env), int(waves_per_block)))
+
+    def launch_geometry(self):
+        g, w = C.c_int(0), C.c_int(0)
+        nat.check(self.h, self.lib.npp_get_launch_geometry(self.h, C.byref(g), C.byref(w)))
+        return g.value, w.value
+
     # ---- stepping ---------------------------------------------------------------------------------------------
     def reset(self, mask=None):
         if mask is None:
