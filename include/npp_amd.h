@@ -42,8 +42,10 @@ enum {
 enum {
     NPP_FLAG_AUTORESET = 1u << 0,         /* reset an env in-kernel when it terminates/truncates
                                              (vector-env semantics; obs returned is the reset obs) */
-    NPP_FLAG_ALLOW_UNSUPPORTED = 1u << 1  /* load levels with unsupported entity types, ignoring
+    NPP_FLAG_ALLOW_UNSUPPORTED = 1u << 1, /* load levels with unsupported entity types, ignoring
                                              those entities (they are skipped, never simulated) */
+    NPP_FLAG_FRAME_CENTERED = 1u << 2     /* player_frame cropped around (x, y) as intended; default (0) reproduces
+                                             the reference's axis-swapped crop (observation_processor.py:219-231) */
 };
 
 /* out_flags bits written by npp_step */

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libnpp_amd.so")
 NPP_OK = 0
 FLAG_AUTORESET = 1
 FLAG_ALLOW_UNSUPPORTED = 2
+FLAG_FRAME_CENTERED = 4
 F_WON, F_DEAD, F_SWITCH, F_TRUNCATED, F_CAUSE_MINE, F_CAUSE_IMPACT = 1, 2, 4, 8, 16, 32
 GAME_STATE_DIM = 41
 DUMP_F64 = 12

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnpp_amd.so")
-SOURCES = ["npp_kernels.hip", "npp_capi.cpp", "npp_level.cpp"]
+SOURCES = ["npp_kernels.hip", "npp_render.hip", "npp_capi.cpp", "npp_level.cpp"]
 HEADERS = ["npp_internal.hpp", "npp_level.hpp", os.path.join("..", "..", "include", "npp_amd.h")]
 
 

@@ -255,6 +255,9 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.off_ent_meta = append(L.ent_meta.data(), 4 * L.ent_meta.size(), 4);
         H.off_init_words = append(L.ent_init_words.data(), 4 * L.ent_init_words.size(), 4);
         H.off_tiles = append(L.tiles.data(), L.tiles.size(), 4);
+        H.off_raster = append(L.raster_order.data(), 2 * L.raster_order.size(), 4);
+        H.off_doors = append(L.door_segs.data(), 8 * L.door_segs.size(), 8);
+        H.n_door = (uint32_t)(L.door_segs.size() / 5);
         H.n_seg = (uint32_t)L.segs.size();
         H.n_ent = (uint32_t)L.ent_x.size();
         H.n_words = (uint32_t)L.ent_init_words.size();
@@ -377,7 +380,7 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_player_frame: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_player_frame: no levels loaded");
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_render(a, d_out, h->stream));
+    HIP_TRY(h, launch_render(a, d_out, (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0, h->stream));
     return NPP_OK;
 }
 

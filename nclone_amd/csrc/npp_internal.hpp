@@ -22,6 +22,9 @@ struct LevelHdr {
     uint32_t off_ent_meta;  // u32[n_ent]
     uint32_t off_init_words;  // u32[n_words]
     uint32_t off_tiles;   // u8[1100]
+    uint32_t off_raster;  // u16[n_ent] draw order
+    uint32_t off_doors;   // f64[5 * n_door]
+    uint32_t n_door;
     uint32_t n_seg;
     uint32_t n_ent;
     uint32_t n_words;
@@ -82,6 +85,6 @@ inline size_t lds_bytes(uint32_t hot_cap, int n_words_max, int envs_per_block) {
 
 hipError_t launch_step(const KernelArgs &a, hipStream_t s);
 hipError_t launch_reset(const KernelArgs &a, hipStream_t s);
-hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
+hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
 
 }  // namespace npp

@@ -1338,7 +1338,6 @@ hipError_t launch_reset(const KernelArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_render(const KernelArgs &, uint8_t *, hipStream_t) { return hipErrorNotSupported; }
 
 #ifdef NPP_STAMPS
 extern "C" int npp_debug_stamps(unsigned long long *out, int n_waves, int reset) {

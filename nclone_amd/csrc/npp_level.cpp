@@ -2,6 +2,7 @@
 #include "npp_level.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 
@@ -69,6 +70,7 @@ struct RawEnt {
     int cell;
     uint32_t init;
     int link_raw;  // index into raw list (door of a switch), -1 otherwise
+    uint32_t type = 0;  // Entity.type (1/21 mine, 2 gold, 3 exit door, 4 exit switch, 6 locked-door switch)
 };
 
 void seg_bounds_units(uint16_t s, int &x0, int &y0, int &x1, int &y1) {
@@ -172,6 +174,7 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
     L.spawn_x = map[1231] * 6;
     L.spawn_y = map[1232] * 6;
     std::vector<RawEnt> raw;
+    std::vector<std::array<double, 5>> raw_doors;
     auto cell_of = [](double px, double py) {
         int cx = clampi((int)std::fmax(std::fmin(std::floor(px / 24), 1e6), -1e6), 0, 43);
         int cy = clampi((int)std::fmax(std::fmin(std::floor(py / 24), 1e6), -1e6), 0, 24);
@@ -187,10 +190,10 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         double xc = map[index + 1], yc = map[index + 2];
         if (type == 1 || type == 21) {
             // type 1 starts toggled/deadly (state 0), type 21 starts untoggled (state 1): entity_factory.py:181-182,230-231
-            raw.push_back({EK_MINE, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), type == 1 ? 0u : 1u, -1});
+            raw.push_back({EK_MINE, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), type == 1 ? 0u : 1u, -1, (uint32_t)type});
             L.n_thinkable++;
         } else if (type == 2) {
-            raw.push_back({EK_GOLD, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 1u, -1});
+            raw.push_back({EK_GOLD, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 1u, -1, 2u});
         } else if (type == 3) {
             int64_t ci = index + 5 * (int64_t)exit_count;
             if (ci + 2 >= n || ci < 0) {
@@ -198,8 +201,8 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
                 return false;
             }
             double sx = map[ci + 1] * 6, sy = map[ci + 2] * 6;
-            raw.push_back({EK_EXIT, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 0u, -1});
-            raw.push_back({EK_SWITCH, sx, sy, cell_of(sx, sy), 1u, (int)raw.size() - 1});
+            raw.push_back({EK_EXIT, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 0u, -1, 3u});
+            raw.push_back({EK_SWITCH, sx, sy, cell_of(sx, sy), 1u, (int)raw.size() - 1, 4u});
             last_switch_raw = (int)raw.size() - 1;
         } else if (type == 6) {
             // the entity lives at its switch (entity_door_base.py:94-97); its door segment never reaches the
@@ -209,7 +212,13 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
                 return false;
             }
             double sx = map[index + 6] * 6, sy = map[index + 7] * 6;
-            raw.push_back({EK_LOCKED, sx, sy, cell_of(sx, sy), 1u, -1});
+            raw.push_back({EK_LOCKED, sx, sy, cell_of(sx, sy), 1u, -1, 6u});
+            {   // the door's stroke (entity_door_base.py:52-85): 24 px long, vertical for orientations 0 and 4
+                double dx = xc * 6, dy = yc * 6, orient = map[index + 3];
+                bool vertical = (orient == 0 || orient == 4);
+                raw_doors.push_back({vertical ? dx : dx - 12, vertical ? dy - 12 : dy, vertical ? dx : dx + 12,
+                                     vertical ? dy + 12 : dy, (double)(raw.size() - 1)});
+            }
         } else if (type == 5 || type == 8 || type == 10 || type == 11 || type == 14 || type == 17 || type == 20 ||
                    type == 24 || type == 25 || type == 26 || type == 28) {
             L.unsupported_mask |= 1u << type;
@@ -247,7 +256,7 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         L.ent_x[s] = r.x;
         L.ent_y[s] = r.y;
         uint32_t link = r.link_raw >= 0 ? (uint32_t)slot_of[r.link_raw] : 0xffffu;
-        L.ent_meta[s] = r.kind | (r.init << 4) | (link << 8);
+        L.ent_meta[s] = r.kind | (r.init << 4) | (link << 8) | (r.type << 24);
         L.ent_init_words[s >> 4] |= r.init << ((s & 15) * 2);
         count[r.cell]++;
     }
@@ -258,6 +267,20 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         acc += count[c];
     }
     L.ent_start[N_CELLS] = (uint16_t)acc;
+    // draw order of the reference's entity layer: groups by Entity.type in order of first appearance while walking
+    // entity_dic keys 1..28 (door 3 before its switch 4), map order inside a group
+    {
+        std::vector<int> ord(raw.size());
+        for (size_t i = 0; i < raw.size(); i++) ord[i] = (int)i;
+        auto rank = [](uint32_t t) { return t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 2 : t == 4 ? 3 : t == 6 ? 4 : 5; };
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return rank(raw[a].type) < rank(raw[b].type); });
+        L.raster_order.resize(raw.size());
+        for (size_t i = 0; i < ord.size(); i++) L.raster_order[i] = (uint16_t)slot_of[ord[i]];
+        for (auto &d : raw_doors) {
+            for (int k = 0; k < 4; k++) L.door_segs.push_back(d[k]);
+            L.door_segs.push_back((double)slot_of[(int)d[4]]);
+        }
+    }
     if (last_switch_raw >= 0) {
         L.obs_switch = slot_of[last_switch_raw];
         L.obs_door = slot_of[raw[last_switch_raw].link_raw];

@@ -30,10 +30,12 @@ struct CompiledLevel {
     std::vector<uint8_t> cell_bounds;  // [N_CELLS]
     std::vector<uint16_t> ent_start;   // [N_CELLS+1] CSR over cells, map order inside a cell, exit doors last
     std::vector<double> ent_x, ent_y;  // [n_ent] pixel positions (coord * 6)
-    std::vector<uint32_t> ent_meta;    // [n_ent] kind | init2bit << 4 | link << 8 (switch -> its door's index)
+    std::vector<uint32_t> ent_meta;    // [n_ent] kind | init2bit << 4 | link << 8 (switch -> its door's index) | raw type << 24
     std::vector<uint16_t> ent_map_order;  // [n_ent] CSR slot of the i-th entity in map order (for dumps)
     std::vector<uint32_t> ent_init_words;  // 2 bits per entity, 16 per word
     std::vector<uint8_t> tiles;        // [N_CELLS] tile id per cell (border = 1), for the rasteriser
+    std::vector<uint16_t> raster_order;  // CSR slots in draw order (entity_renderer.py:100-150: by type, then map order)
+    std::vector<double> door_segs;     // closed-door strokes: x1, y1, x2, y2, slot of the owning entity (5 per door)
     double spawn_x = 0, spawn_y = 0;
     int obs_switch = -1, obs_door = -1;  // CSR slots of the exit switch / door reported in observations
     int n_thinkable = 0;               // mines

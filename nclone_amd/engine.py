@@ -31,13 +31,14 @@ class NppBatch:
     Counterpart of N instances of the reference's NPlayHeadless (nclone/nplay_headless.py:28).
     """
 
-    def __init__(self, n_envs, device=0, autoreset=True, allow_unsupported=False):
+    def __init__(self, n_envs, device=0, autoreset=True, allow_unsupported=False, frame_centered=False):
         self.lib = nat.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("nclone_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.n = int(n_envs)
         self.device = torch.device("cuda", int(device))
-        flags = (nat.FLAG_AUTORESET if autoreset else 0) | (nat.FLAG_ALLOW_UNSUPPORTED if allow_unsupported else 0)
+        flags = ((nat.FLAG_AUTORESET if autoreset else 0) | (nat.FLAG_ALLOW_UNSUPPORTED if allow_unsupported else 0)
+                 | (nat.FLAG_FRAME_CENTERED if frame_centered else 0))
         h = C.c_void_p()
         nat.check(None, self.lib.npp_create(self.n, int(device), flags, C.byref(h)))
         self.h = h
@@ -127,6 +128,11 @@ class NppBatch:
 
     def observe(self):
         nat.check(self.h, self.lib.npp_observe(self.h, C.byref(self._out_min)))
+
+    def render_player_frame(self, out):
+        """out: uint8 CUDA tensor [N, 84, 84] (or [N, 84, 84, 1]) filled with the player_frame of every env."""
+        assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 84 * 84 and out.is_contiguous()
+        nat.check(self.h, self.lib.npp_render_player_frame(self.h, C.c_void_p(out.data_ptr())))
 
     def sync(self):
         nat.check(self.h, self.lib.npp_sync(self.h))

@@ -1,0 +1,254 @@
+"""Gymnasium-shaped host classes over the native stepper.
+
+  NppVecEnvironment  N environments per object; the same observation keys as the reference's NppEnvironment with a
+                     leading batch dimension (nclone/gym_environment/npp_environment.py:504 reset,
+                     base_environment.py:483 step).
+  NppEnvironment     one environment, literal drop-in signatures: reset() -> (obs, info),
+                     step(int) -> (obs, float, bool, bool, dict).
+  NPlayHeadless      the facade the reference's tools drive (nclone/nplay_headless.py:28): load_map_from_map_data,
+                     reset, tick(h, j), ninja_has_won/died, ninja_position, get_ninja_state, ...
+
+Everything executes in the HIP kernels; nothing here falls back to the CPU.
+"""
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import spaces
+from .engine import NppBatch
+
+ACTION_TABLE = [(0, 0), (-1, 0), (1, 0), (0, 1), (-1, 1), (1, 1)]  # base_environment.py:366-402
+DEATH_CAUSES = {0: None, 1: "mine", 2: "terminal_impact"}
+
+
+def controls_to_input_byte(hor, jump):
+    """(hor, jump) -> replay input byte (bit0 jump, bit1 right, bit2 left; replay/replay_executor.py:61-84)."""
+    return (1 if jump else 0) | (2 if hor > 0 else 0) | (4 if hor < 0 else 0)
+
+
+class NppVecEnvironment:
+    """N N++ environments stepped in lock-step on one MI355X.
+
+    levels      sequence of raw map_data arrays (ints/floats/bytes)
+    level_ids   which level each env plays (default: env i plays level (i // 64) % n_levels, so every 64-env block
+                shares a level and the kernel stages it in LDS)
+    output      "torch" (CUDA tensors, zero copies) or "numpy" (host copies; drop-in for numpy training loops)
+    """
+
+    metadata = {"render_modes": []}
+
+    def __init__(self, levels, num_envs, level_ids=None, frame_skip=4, device=0, enable_visual_observations=False,
+                 truncation_limit=10000, output="torch", autoreset=True):
+        assert output in ("torch", "numpy")
+        self.num_envs = int(num_envs)
+        self.frame_skip = int(frame_skip)
+        self.output = output
+        self.enable_visual_observations = bool(enable_visual_observations)
+        self.single_action_space = spaces.action_space()
+        self.single_observation_space = spaces.observation_space(self.enable_visual_observations)
+        self.action_space = self.single_action_space
+        self.observation_space = self.single_observation_space
+        self._b = NppBatch(self.num_envs, device=device, autoreset=autoreset)
+        self._b.load_levels(levels)
+        if level_ids is None:
+            level_ids = (np.arange(self.num_envs) // 64) % len(levels)
+        self._b.assign_levels(level_ids)
+        self._b.set_truncation_limit(truncation_limit)
+        self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
+        self._frame = None
+        if self.enable_visual_observations:
+            self._frame = torch.zeros((self.num_envs, 84, 84, 1), dtype=torch.uint8, device=self._b.device)
+
+    # -- helpers ------------------------------------------------------------------------------------------------
+    def _conv(self, t):
+        return t if self.output == "torch" else t.cpu().numpy()
+
+    def _obs(self):
+        b = self._b
+        obs = {
+            "game_state": self._conv(b.game_state),
+            "action_mask": self._conv(b.action_mask),
+            "entity_positions": self._conv(b.entity_pos),
+        }
+        if self._frame is not None:
+            b.render_player_frame(self._frame)
+            obs["player_frame"] = self._conv(self._frame)
+        return obs
+
+    # -- Gymnasium surface ----------------------------------------------------------------------------------------
+    def reset(self, seed=None, options=None):
+        """Reset every env to its level's spawn state (npp_environment.py:504; fast path nsim.py:78)."""
+        self._b.reset()
+        self._b.observe()
+        return self._obs(), {}
+
+    def step(self, actions):
+        """actions: int array/tensor [N] in 0..5.  Returns (obs, reward, terminated, truncated, info) with batch dims."""
+        b = self._b
+        if isinstance(actions, torch.Tensor):
+            self._actions.copy_(actions.to(torch.uint8), non_blocking=True)
+        else:
+            self._actions.copy_(torch.as_tensor(np.asarray(actions, dtype=np.uint8)), non_blocking=True)
+        b.step(self._actions, self.frame_skip, want_terminal=True)
+        flags = b.flags
+        terminated = (flags & 3) != 0
+        truncated = (flags & 8) != 0
+        info = {
+            "player_won": self._conv((flags & 1) != 0),
+            "player_dead": self._conv((flags & 2) != 0),
+            "switch_activated": self._conv((flags & 4) != 0),
+            "death_cause_code": self._conv((flags >> 4) & 3),
+            "frames_executed": self._conv(b.frames),
+            "terminal_observation": self._conv(b.terminal_state),
+            "frame_skip_stats": {"skip_value": self.frame_skip},
+        }
+        return self._obs(), self._conv(b.reward), self._conv(terminated), self._conv(truncated), info
+
+    def close(self):
+        self._b.close()
+
+    @property
+    def batch(self):
+        return self._b
+
+
+class NppEnvironment:
+    """Single-environment adapter with the reference's exact call signatures (base_environment.py:483,
+    npp_environment.py:504).  One GPU lane group does the work of one Python simulator; use NppVecEnvironment for
+    throughput."""
+
+    def __init__(self, map_data=None, custom_map_path=None, frame_skip=4, device=0, enable_visual_observations=False,
+                 truncation_limit=10000):
+        if map_data is None:
+            if custom_map_path is None:
+                raise ValueError("NppEnvironment needs map_data or custom_map_path")
+            with open(custom_map_path, "rb") as f:
+                map_data = np.frombuffer(f.read(), dtype=np.uint8)
+        self._v = NppVecEnvironment([map_data], 1, level_ids=[0], frame_skip=frame_skip, device=device,
+                                    enable_visual_observations=enable_visual_observations,
+                                    truncation_limit=truncation_limit, output="numpy", autoreset=False)
+        self.action_space = self._v.single_action_space
+        self.observation_space = self._v.single_observation_space
+        self.frame_skip = frame_skip
+
+    @staticmethod
+    def _unbatch(obs):
+        return {k: v[0] for k, v in obs.items()}
+
+    def reset(self, seed=None, options=None):
+        obs, info = self._v.reset(seed=seed, options=options)
+        return self._unbatch(obs), info
+
+    def step(self, action):
+        obs, rew, term, trunc, info = self._v.step(np.array([int(action)], dtype=np.uint8))
+        cause = DEATH_CAUSES[int(info["death_cause_code"][0])]
+        out_info = {
+            "player_won": bool(info["player_won"][0]),
+            "player_dead": bool(info["player_dead"][0]),
+            "switch_activated": bool(info["switch_activated"][0]),
+            "death_cause": cause,
+            "frame_skip_stats": {"skip_value": self.frame_skip, "frames_executed": int(info["frames_executed"][0])},
+        }
+        return self._unbatch(obs), float(rew[0]), bool(term[0]), bool(trunc[0]), out_info
+
+    def close(self):
+        self._v.close()
+
+
+class _SimView:
+    """`.sim.frame` of the facade."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def frame(self):
+        return int(self._o._state()[1][0, 22])
+
+
+class NPlayHeadless:
+    """The reference's headless facade for one simulator, backed by the GPU stepper (nplay_headless.py:28).
+
+    Method names, argument meaning and return conventions follow the reference so that harnesses such as
+    tools/test_replay_playback.py read the same."""
+
+    def __init__(self, device=0, enable_rendering=False, **_ignored):
+        self._device = device
+        self._b = None
+        self.sim = _SimView(self)
+        self.current_map_data = None
+
+    def load_map_from_map_data(self, map_data):
+        if self._b is not None:
+            self._b.close()
+        self._b = NppBatch(1, device=self._device, autoreset=False)
+        self._b.load_levels([map_data])
+        self._in = torch.zeros((1, 1), dtype=torch.uint8, device=self._b.device)
+        self.current_map_data = map_data
+
+    def load_map(self, map_path):
+        with open(map_path, "rb") as f:
+            self.load_map_from_map_data(np.frombuffer(f.read(), dtype=np.uint8))
+
+    def reset(self):
+        self._b.reset()
+
+    def fast_reset(self):
+        self._b.reset()
+
+    def tick(self, horizontal_input, jump_input):
+        self._in.fill_(controls_to_input_byte(horizontal_input, jump_input))
+        self._b.tick(self._in)
+
+    def _state(self):
+        return self._b.dump_state(0, 1)
+
+    def ninja_has_won(self):
+        return int(self._state()[1][0, 0]) == 8
+
+    def ninja_has_died(self):
+        return int(self._state()[1][0, 0]) in (6, 7)
+
+    def ninja_death_cause(self):
+        return DEATH_CAUSES[int(self._state()[1][0, 20])]
+
+    def ninja_position(self):
+        f = self._state()[0][0]
+        return float(f[0]), float(f[1])
+
+    def ninja_velocity(self):
+        f = self._state()[0][0]
+        return float(f[2]), float(f[3])
+
+    def ninja_velocity_old(self):
+        f = self._state()[0][0]
+        return float(f[8]), float(f[9])
+
+    def get_ninja_terminal_impact(self):
+        return bool(self._state()[1][0, 21])
+
+    def get_ninja_state(self):
+        self._b.observe()
+        return [float(v) for v in self._b.game_state[0, :40].cpu().numpy()]
+
+    def get_action_mask(self):
+        self._b.observe()
+        return [bool(v) for v in self._b.action_mask[0].cpu().numpy()]
+
+    def exit_switch_activated(self):
+        return int(self._state()[1][0, 13]) != 1
+
+    def exit_switch_position(self):
+        self._b.observe()
+        p = self._b.entity_pos[0].cpu().numpy().astype(np.float64)
+        return float(p[2] * 1056.0), float(p[3] * 600.0)
+
+    def exit_door_position(self):
+        self._b.observe()
+        p = self._b.entity_pos[0].cpu().numpy().astype(np.float64)
+        return float(p[4] * 1056.0), float(p[5] * 600.0)
+
+    def exit(self):
+        if self._b is not None:
+            self._b.close()
+            self._b = None

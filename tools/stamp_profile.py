@@ -22,7 +22,7 @@ def main():
     csrc = os.path.join(ROOT, "nclone_amd", "csrc")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                            "-DNPP_STAMPS", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-o", out] +
-                          [os.path.join(csrc, f) for f in ("npp_kernels.hip", "npp_capi.cpp", "npp_level.cpp")])
+                          [os.path.join(csrc, f) for f in ("npp_kernels.hip", "npp_render.hip", "npp_capi.cpp", "npp_level.cpp")])
     nat.LIB_PATH = out
     from nclone_amd.engine import NppBatch
     from nclone_amd.levels import curriculum0_levels
