@@ -223,6 +223,15 @@ def main():
             traj["d%d" % i] = np.array(drows, dtype=np.uint8).reshape(-1, N_DISC)
             gst["g%d" % i] = np.array(grows, dtype=np.float64).astype(np.float32).reshape(-1, 40)
             gst["k%d" % i] = np.array(krows, dtype=np.uint8)
+    # two raw replay files (data the reference's corpus holds) for the file-format parser: one per header version
+    for want, key in ((0, "raw_v0"), (1, "raw_v1")):
+        for f in files:
+            data = open(f, "rb").read()
+            is_v1 = struct.unpack("<I", data[:4])[0] <= 100
+            if int(is_v1) == want:
+                corpus[key] = np.frombuffer(data, dtype=np.uint8)
+                corpus[key + "_index"] = np.array([files.index(f)])
+                break
     corpus["names"] = np.frombuffer("\n".join(names).encode(), dtype=np.uint8)
     corpus["sigs"] = np.frombuffer("\n".join(sigs).encode(), dtype=np.uint8)
     corpus["final"] = final

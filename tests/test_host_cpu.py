@@ -1,0 +1,120 @@
+"""CPU-only checks of the product's host side: the native level compiler against the reference's ordered segment
+and entity dumps, the C ABI surface (every symbol declared in include/npp_amd.h is exported), loud failure
+without a GPU, replay file format, host helpers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from nclone_amd import build_native
+
+    build_native.build()
+    from nclone_amd import _native
+
+    return _native
+
+
+def test_header_symbols_exported(native):
+    hdr = open(os.path.join(ROOT, "include", "npp_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(npp_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = C.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(native.EXPORTS) == declared
+
+
+def test_level_compiler_matches_reference_tables(native, golden):
+    from nclone_amd.engine import compile_level_entities, compile_level_segments
+
+    c, csr, lg = golden.z("corpus"), golden.z("csr"), golden.z("levels_gen")
+    kind = {1: 1, 21: 1, 2: 2, 3: 3, 4: 4, 6: 6}
+    sigs = golden.names("corpus", "sigs")
+    for i in range(len(sigs)):
+        m = c["m%d" % i].astype(np.float64)
+        rows, uns = compile_level_segments(m)
+        assert np.array_equal(rows, csr[bytes(c["csr%d" % i]).decode()]), i
+        types = set(int(x) for x in sigs[i].split(",") if x)
+        assert (uns != 0) == (not types <= {1, 2, 3, 6, 21})
+        if "ent%d" % i in c.files:
+            ref = sorted((kind[int(t)], x, y, cx, cy) for _, t, x, y, cx, cy, _, _ in c["ent%d" % i])
+            got = sorted((int(k), x, y, cx, cy) for k, x, y, cx, cy, _ in compile_level_entities(m))
+            assert ref == got, i
+    for k in range(len(golden.names("levels_gen"))):
+        rows, uns = compile_level_segments(lg["L%d" % k])
+        assert uns == 0 and np.array_equal(rows, csr[bytes(lg["csr%d" % k]).decode()]), k
+        ref = sorted((kind[int(t)], x, y, cx, cy) for _, t, x, y, cx, cy, _, _ in lg["ent%d" % k])
+        got = sorted((int(kk), x, y, cx, cy) for kk, x, y, cx, cy, _ in compile_level_entities(lg["L%d" % k]))
+        assert ref == got, k
+
+
+def test_level_compiler_edge_cases(native):
+    from nclone_amd._native import NppError
+    from nclone_amd.engine import compile_level_entities, compile_level_segments
+
+    with pytest.raises(NppError):
+        compile_level_segments(np.zeros(100))            # too short
+    empty = np.zeros(1245)
+    empty[1231], empty[1232] = 10, 10
+    rows, uns = compile_level_segments(empty)             # empty interior: the border ring's inner and outer half-edges
+    inner, outer = 2 * (2 * 42 + 2 * 23), 2 * (2 * 44 + 2 * 25)
+    assert uns == 0 and len(rows) == inner + outer
+    assert len(compile_level_entities(empty)) == 0
+    full = empty.copy()
+    full[184:1150] = 1                                    # solid interior: every edge cancels
+    assert len(compile_level_segments(full)[0]) == outer
+    glitch = empty.copy()
+    glitch[184:1150] = 35                                 # glitched tiles 34..37 are empty for collision
+    assert len(compile_level_segments(glitch)[0]) == len(rows)
+
+
+def test_no_gpu_fails_loudly(native):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nclone_amd.engine import NppBatch
+
+    with pytest.raises(RuntimeError):
+        NppBatch(4)
+    h = C.c_void_p()
+    rc = native.lib().npp_create(4, 0, 0, C.byref(h))
+    assert rc != 0 and b"no HIP device" in native.lib().npp_last_error(None)
+
+
+def test_replay_format_v0_v1(golden):
+    from nclone_amd.replay import CompactReplay, decode_input_to_controls
+
+    c = golden.z("corpus")
+    for key, ver in (("raw_v0", 0), ("raw_v1", 1)):
+        raw = bytes(c[key])
+        i = int(c[key + "_index"][0])
+        r = CompactReplay.from_binary(raw)
+        assert r.version == ver
+        assert r.map_data == bytes(c["m%d" % i]) and r.input_sequence == list(c["in%d" % i])
+        r2 = CompactReplay.from_binary(r.to_binary())
+        assert r2.map_data == r.map_data and r2.input_sequence == r.input_sequence and r2.version == 1
+    assert [decode_input_to_controls(b) for b in range(8)] == [(0, 0), (0, 1), (1, 0), (1, 1), (-1, 0), (-1, 1), (0, 0), (0, 1)]
+
+
+def test_host_helpers():
+    from nclone_amd import spaces
+    from nclone_amd.distributed import shard_envs
+    from nclone_amd.vec_env import ACTION_TABLE, controls_to_input_byte
+    from nclone_amd.replay import decode_input_to_controls
+
+    assert spaces.action_space().n == 6
+    obs = spaces.observation_space(True)
+    assert obs["game_state"].shape == (41,) and obs["player_frame"].shape == (84, 84, 1)
+    for hor, jump in ACTION_TABLE:
+        assert decode_input_to_controls(controls_to_input_byte(hor, jump)) == (hor, jump)
+    parts = [shard_envs(65536 + 3, r, 8) for r in range(8)]
+    assert sum(c for _, c in parts) == 65539 and parts[0][0] == 0
+    assert all(parts[k][0] + parts[k][1] == parts[k + 1][0] for k in range(7))

@@ -1,0 +1,116 @@
+"""The CPU oracle (oracle/nsim_oracle.c) against fixtures produced by RUNNING the reference
+(tests/golden/make_golden.py).  Bit-exact: fp64 positions/velocities and every discrete field.
+These tests pin the oracle; the GPU tests then compare the HIP path with the oracle and the same fixtures."""
+import numpy as np
+import pytest
+
+
+def test_oracle_replays_bit_exact(golden, oracle_mod):
+    c, t = golden.z("corpus"), golden.z("traj")
+    idx = golden.in_scope_replays()
+    assert len(idx) == 104
+    ticks = 0
+    for i in idx:
+        o = oracle_mod.Oracle("pow")
+        assert o.load(c["m%d" % i].astype(np.float64)) == 0
+        T, D = t["t%d" % i], t["d%d" % i]
+        for k in range(len(T)):
+            h, j = oracle_mod.controls(int(c["in%d" % i][k]))
+            o.tick(h, j)
+            f, d = o.core()
+            assert np.array_equal(f[:4], T[k]), (i, k)
+            assert np.array_equal(d[:20].clip(0, 255), D[k]), (i, k)
+            ticks += 1
+        final = c["final"][i]
+        assert int(final[0]) == len(T) and d[0] == int(final[1])
+    assert ticks == 25575
+
+
+def test_oracle_very_simple_100001_known_answers(golden, oracle_mod):
+    """replay 20251022_142001_train_very_simple_100001: 37 inputs, win at tick 37,
+    final position (812.0036311681246, 542.0), spawn (828, 540)."""
+    c = golden.z("corpus")
+    names = golden.names("corpus")
+    i = names.index("20251022_142001_train_very_simple_100001")
+    o = oracle_mod.Oracle("pow")
+    o.load(c["m%d" % i].astype(np.float64))
+    f, d = o.core()
+    assert (f[0], f[1]) == (828.0, 540.0)
+    for k, b in enumerate(c["in%d" % i]):
+        h, j = oracle_mod.controls(int(b))
+        o.tick(h, j)
+        f, d = o.core()
+        if d[0] == 8:
+            break
+    assert k + 1 == 37 and (f[0], f[1]) == (812.0036311681246, 542.0)
+
+
+@pytest.mark.parametrize("variant", ["pow", "mul"])
+def test_oracle_rollouts(golden, oracle_mod, variant):
+    """Random-action frame-skip rollouts with reset on termination.  The libm-pow variant must match the reference's
+    bits; the multiply-square variant (what the GPU computes) must too on this corpus."""
+    r = golden.z("rollouts")
+    names = golden.names("rollouts")
+    for i in range(len(names)):
+        o = oracle_mod.Oracle(variant)
+        assert o.load(r["m%d" % i]) == 0
+        T, D, S, G, K = r["t%d" % i], r["d%d" % i], r["s%d" % i], r["g%d" % i], r["k%d" % i]
+        row = 0
+        for s, a in enumerate(r["a%d" % i]):
+            ex, fl = o.env_step(int(a), 4)
+            f, d = o.core()
+            row += ex
+            assert (ex, fl, o.frame) == tuple(S[s]), (names[i], s)
+            assert np.array_equal(f[:4], T[row - 1]), (names[i], s)
+            assert np.array_equal(d[:20].clip(0, 255), D[row - 1]), (names[i], s)
+            if variant == "pow":
+                assert np.array_equal(o.ninja_state().astype(np.float32), G[s]), (names[i], s)
+                assert o.action_mask() == K[s]
+            if fl:
+                o.reset()
+
+
+def test_oracle_game_state_and_mask_on_replays(golden, oracle_mod):
+    c, g = golden.z("corpus"), golden.z("gstate")
+    for i in golden.in_scope_replays()[::4]:
+        o = oracle_mod.Oracle("pow")
+        o.load(c["m%d" % i].astype(np.float64))
+        G, K = g["g%d" % i], g["k%d" % i]
+        for k in range(len(G)):
+            h, j = oracle_mod.controls(int(c["in%d" % i][k]))
+            o.tick(h, j)
+            assert np.array_equal(o.ninja_state().astype(np.float32), G[k]), (i, k)
+            assert o.action_mask() == K[k]
+
+
+def test_oracle_level_tables(golden, oracle_mod):
+    """Ordered per-cell segment lists (first-hit-wins order matters) and entity tables of all 130 + 112 levels."""
+    c, csr, lg = golden.z("corpus"), golden.z("csr"), golden.z("levels_gen")
+    for i in range(len(golden.names("corpus"))):
+        o = oracle_mod.Oracle("pow")
+        o.load(c["m%d" % i].astype(np.float64))
+        assert np.array_equal(o.dump_csr(), csr[bytes(c["csr%d" % i]).decode()]), i
+        if "ent%d" % i in c.files:
+            ref = c["ent%d" % i]
+            got = o.dump_entities()
+            assert np.array_equal(got[:, :6], ref[:, :6]) and np.array_equal(got[:, 7], ref[:, 7]), i
+            mine = ref[:, 6] >= 0
+            assert np.array_equal(got[mine, 6], ref[mine, 6])
+    for k in range(len(golden.names("levels_gen"))):
+        o = oracle_mod.Oracle("pow")
+        assert o.load(lg["L%d" % k]) == 0
+        assert np.array_equal(o.dump_csr(), csr[bytes(lg["csr%d" % k]).decode()]), k
+        assert np.array_equal(o.dump_entities()[:, :6], lg["ent%d" % k][:, :6]), k
+
+
+def test_oracle_unsupported_entities_flagged(golden, oracle_mod):
+    c = golden.z("corpus")
+    sigs = golden.names("corpus", "sigs")
+    seen = 0
+    for i, s in enumerate(sigs):
+        types = set(int(x) for x in s.split(",") if x)
+        o = oracle_mod.Oracle("pow")
+        uns = o.load(c["m%d" % i].astype(np.float64))
+        assert (uns != 0) == (not types <= {1, 2, 3, 6, 21}), (i, s, uns)
+        seen += uns != 0
+    assert seen == 26
