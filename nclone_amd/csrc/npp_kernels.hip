@@ -92,6 +92,14 @@ struct Lv {
     double spawn_x, spawn_y, sw_x, sw_y, door_x, door_y;
 };
 
+// the three collision tables, passed BY VALUE to the out-of-line fallbacks so that nothing the hot loop touches
+// has to live in (scratch) memory
+struct TileRefs {
+    const uint16_t *seg_start;
+    const uint16_t *segs;
+    const uint8_t *bounds;
+};
+
 DEV double sq(double v) { return v * v; }
 DEV double dabs(double v) { return __builtin_fabs(v); }
 DEV double dsqrt(double v) { return __builtin_sqrt(v); }
@@ -404,80 +412,107 @@ DEV bool cell_passes(uint32_t cb, int xc, int yc, double qx0, double qy0, double
 // answered from registers by applying the reference's own filters per candidate (cell range, inclusive cell-bounds
 // test, per-segment AABB test) -- the surviving candidates in flat order are exactly the reference's list.  A query
 // that leaves the region (or a region with more segments than lanes x slots) falls back to the LDS walk below.
+// All filters are evaluated in doubles on exact quantities (multiples of 12 px), so no integer cell arithmetic is
+// needed on the fast path.
 template <int G> struct KSlots { static constexpr int value = G >= 32 ? 1 : (G >= 16 ? 2 : 4); };
 
-struct Query {
-    int c0x, c1x, c0y, c1y;   // clamped cell range (utils/spatial_segment_index.py:131-134)
-    int fx1, cx0, fy1, cy0;   // floor(max / 12), ceil(min / 12): the inclusive cell-bounds test (:186-188) in ints
+DEV double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// A query box plus copies clamped to the map: clamp(floor(q / 24), 0, 43) == floor(clamp(q, 0, 1032) / 24) and
+// likewise with 576 for y (utils/spatial_segment_index.py:131-134), so "cell xc is inside the query's clamped cell
+// range" is 24 xc <= clamp(qx1) && 24 (xc + 1) > clamp(qx0).
+struct QBox {
+    double x0, y0, x1, y1;
+    double cx0, cy0, cx1, cy1;
 };
-DEV Query make_query(double qx0, double qy0, double qx1, double qy1) {
-    Query q;
-    int f0x = floor12(qx0), f0y = floor12(qy0);
-    q.fx1 = floor12(qx1);
-    q.fy1 = floor12(qy1);
-    q.cx0 = f0x + ((12.0 * f0x != qx0) ? 1 : 0);
-    q.cy0 = f0y + ((12.0 * f0y != qy0) ? 1 : 0);
-    q.c0x = clampi(f0x >> 1, 0, 43); q.c1x = clampi(q.fx1 >> 1, 0, 43);
-    q.c0y = clampi(f0y >> 1, 0, 24); q.c1y = clampi(q.fy1 >> 1, 0, 24);
+DEV QBox make_qbox(double x0, double y0, double x1, double y1) {
+    QBox q;
+    q.x0 = x0; q.y0 = y0; q.x1 = x1; q.y1 = y1;
+    q.cx0 = clampd(x0, 0.0, 1032.0); q.cx1 = clampd(x1, 0.0, 1032.0);
+    q.cy0 = clampd(y0, 0.0, 576.0); q.cy1 = clampd(y1, 0.0, 576.0);
     return q;
 }
 
 template <int K> struct Cand {
-    int rc0x, rc1x, rc0y, rc1y;   // gathered cell range
+    double rx0, ry0, rx1, ry1;   // gathered cell range in pixels: [24 c0, 24 (c1 + 1))
     bool ok;
-    uint32_t s[K];      // packed segment (bits 0-15, incl. cell y) | cell x << 16 | valid << 31
-    uint32_t babs[K];   // the owning cell's bounds in absolute 12-px units: x0 | y0 << 8 | x1 << 16 | y1 << 24
-    double x1[K], y1[K], x2[K], y2[K];   // linear: end points; arc: centre, p_hor.x, p_ver.y
+    uint32_t s[K];               // packed segment (bits 0-15, incl. cell y) | cell x << 16 | valid << 31
+    double x1[K], y1[K], x2[K], y2[K];       // linear: end points; arc: centre, p_hor.x, p_ver.y
+    double wx[K], wy[K], l2[K], rl2[K];      // linear: segment vector, |w|^2 and RN(1 / |w|^2)
+    double ox[K], oy[K];                     // origin of the owning cell
+    double bx0[K], by0[K], bx1[K], by1[K];   // the owning cell's bounds over its segments (:86-105)
 };
 
 template <int G, int K>
-DEV void cand_gather(const Lv &lv, int r, double bx0, double by0, double bx1, double by1, Cand<K> &c) {
-    Query q = make_query(bx0, by0, bx1, by1);
-    c.rc0x = q.c0x; c.rc1x = q.c1x; c.rc0y = q.c0y; c.rc1y = q.c1y;
-    const int ncol = q.c1x - q.c0x + 1;
-    int a0 = lv.seg_start[q.c0x * 25 + q.c0y], n0 = lv.seg_start[q.c0x * 25 + q.c1y + 1] - a0;
+DEV void cand_gather(const Lv &lv, int r, double qx0, double qy0, double qx1, double qy1, Cand<K> &c) {
+    const int c0x = cell_coord(qx0, 43), c1x = cell_coord(qx1, 43), c0y = cell_coord(qy0, 24), c1y = cell_coord(qy1, 24);
+    c.rx0 = 24.0 * c0x; c.rx1 = 24.0 * (c1x + 1); c.ry0 = 24.0 * c0y; c.ry1 = 24.0 * (c1y + 1);
+    const int ncol = c1x - c0x + 1;
+    int a0 = lv.seg_start[c0x * 25 + c0y], n0 = lv.seg_start[c0x * 25 + c1y + 1] - a0;
     int a1 = 0, n1 = 0, a2 = 0, n2 = 0;
-    if (ncol > 1) { a1 = lv.seg_start[(q.c0x + 1) * 25 + q.c0y]; n1 = lv.seg_start[(q.c0x + 1) * 25 + q.c1y + 1] - a1; }
-    if (ncol > 2) { a2 = lv.seg_start[(q.c0x + 2) * 25 + q.c0y]; n2 = lv.seg_start[(q.c0x + 2) * 25 + q.c1y + 1] - a2; }
+    if (ncol > 1) { a1 = lv.seg_start[(c0x + 1) * 25 + c0y]; n1 = lv.seg_start[(c0x + 1) * 25 + c1y + 1] - a1; }
+    if (ncol > 2) { a2 = lv.seg_start[(c0x + 2) * 25 + c0y]; n2 = lv.seg_start[(c0x + 2) * 25 + c1y + 1] - a2; }
     const int total = n0 + n1 + n2;
     c.ok = ncol <= 3 && total <= G * K;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         int f = k * G + r;
-        c.s[k] = 0; c.babs[k] = 0; c.x1[k] = 0; c.y1[k] = 0; c.x2[k] = 0; c.y2[k] = 0;
+        c.s[k] = 0;
+        c.x1[k] = 0; c.y1[k] = 0; c.x2[k] = 0; c.y2[k] = 0; c.wx[k] = 0; c.wy[k] = 0; c.l2[k] = 1; c.rl2[k] = 1;
+        c.ox[k] = 0; c.oy[k] = 0; c.bx0[k] = 0; c.by0[k] = 0; c.bx1[k] = 0; c.by1[k] = 0;
         if (c.ok && f < total) {
-            int xc = q.c0x, i = a0 + f;
+            int xc = c0x, i = a0 + f;
             if (f >= n0) { xc += 1; i = a1 + (f - n0); }
             if (f >= n0 + n1) { xc += 1; i = a2 + (f - n0 - n1); }
             uint32_t s = lv.segs[i];
             int yc = s >> 11;
             uint32_t cb = lv.bounds[xc * 25 + yc];
             c.s[k] = s | ((uint32_t)xc << 16) | 0x80000000u;
-            c.babs[k] = (2 * xc + (cb & 3)) | ((2 * yc + ((cb >> 2) & 3)) << 8) | ((2 * xc + ((cb >> 4) & 3)) << 16) |
-                        ((2 * yc + ((cb >> 6) & 3)) << 24);
             double ox = 24.0 * xc, oy = 24.0 * yc;
+            c.ox[k] = ox; c.oy[k] = oy;
+            c.bx0[k] = ox + 12.0 * (cb & 3); c.by0[k] = oy + 12.0 * ((cb >> 2) & 3);
+            c.bx1[k] = ox + 12.0 * ((cb >> 4) & 3); c.by1[k] = oy + 12.0 * ((cb >> 6) & 3);
+            c.x1[k] = ox + 12.0 * ((s >> 2) & 3); c.y1[k] = oy + 12.0 * ((s >> 4) & 3);
             if ((s & 1u) == 0) {
-                c.x1[k] = ox + 12.0 * ((s >> 2) & 3); c.y1[k] = oy + 12.0 * ((s >> 4) & 3);
                 c.x2[k] = ox + 12.0 * ((s >> 6) & 3); c.y2[k] = oy + 12.0 * ((s >> 8) & 3);
+                int wxu = (int)((s >> 6) & 3) - (int)((s >> 2) & 3), wyu = (int)((s >> 8) & 3) - (int)((s >> 4) & 3);
+                int aw = wxu * wxu + wyu * wyu;   // |w|^2 / 144: 1 axis aligned, 8 at 45 degrees, 5 for the 1:2 slopes
+                c.wx[k] = 12.0 * wxu; c.wy[k] = 12.0 * wyu;
+                c.l2[k] = aw == 1 ? 144.0 : (aw == 8 ? 1152.0 : 720.0);
+                c.rl2[k] = aw == 1 ? 1.0 / 144.0 : (aw == 8 ? 1.0 / 1152.0 : 1.0 / 720.0);
+                if (!(aw == 1 || aw == 8 || aw == 5)) c.ok = false;   // never produced by the tile tables
             } else {
-                c.x1[k] = ox + 12.0 * ((s >> 2) & 3); c.y1[k] = oy + 12.0 * ((s >> 4) & 3);
                 c.x2[k] = c.x1[k] + (((s >> 6) & 1) ? 24.0 : -24.0);   // p_hor.x (entities.py:113)
                 c.y2[k] = c.y1[k] + (((s >> 7) & 1) ? 24.0 : -24.0);   // p_ver.y (entities.py:114)
             }
         }
     }
+    if constexpr (G > 1) {   // the "unexpected segment length" veto must be group-wide
+        const int glane0 = (threadIdx.x & 63) & ~(G - 1);
+        unsigned long long bad = __ballot(!c.ok) >> glane0;
+        if constexpr (G < 64) bad &= (1ull << G) - 1;
+        c.ok = bad == 0;
+    }
 }
 
-template <int K> DEV bool cand_covers(const Cand<K> &c, const Query &q) {
-    return c.ok && q.c0x >= c.rc0x && q.c1x <= c.rc1x && q.c0y >= c.rc0y && q.c1y <= c.rc1y;
+template <int K> DEV bool cand_covers(const Cand<K> &c, const QBox &q) {
+    return c.ok & (q.cx0 >= c.rx0) & (q.cx1 < c.rx1) & (q.cy0 >= c.ry0) & (q.cy1 < c.ry1);
 }
 
-// would the reference's query have returned this candidate?  (cell inside the query's range + cell-bounds test)
-DEV bool cand_in_query(uint32_t sk, uint32_t babs, const Query &q) {
-    int xc = (sk >> 16) & 63, yc = (sk >> 11) & 31;
-    bool in = (sk >> 31) && xc >= q.c0x && xc <= q.c1x && yc >= q.c0y && yc <= q.c1y;
-    int b0 = babs & 255, b1 = (babs >> 8) & 255, b2 = (babs >> 16) & 255, b3 = babs >> 24;
-    return in && b0 <= q.fx1 && b2 >= q.cx0 && b1 <= q.fy1 && b3 >= q.cy0;
+// would the reference's query have returned candidate k?  (its cell inside the query's clamped cell range and the
+// inclusive cell-bounds test of utils/spatial_segment_index.py:186-188)
+template <int K> DEV bool cand_in_box(const Cand<K> &c, int k, const QBox &q) {
+    bool in_range = (c.ox[k] <= q.cx1) & (c.ox[k] + 24.0 > q.cx0) & (c.oy[k] <= q.cy1) & (c.oy[k] + 24.0 > q.cy0);
+    bool reject = (q.x1 < c.bx0[k]) | (q.x0 > c.bx1[k]) | (q.y1 < c.by0[k]) | (q.y0 > c.by1[k]);
+    return (c.s[k] >> 31) & in_range & !reject;
+}
+
+template <int G> DEV bool group_any(bool v) {
+    if constexpr (G == 1) return v;
+    const int glane0 = (threadIdx.x & 63) & ~(G - 1);
+    unsigned long long bal = __ballot(v) >> glane0;
+    if constexpr (G < 64) bal &= (1ull << G) - 1;
+    return bal != 0;
 }
 
 // intersect_with_ray on a decoded candidate (entities.py:82-96,180-203)
@@ -501,23 +536,9 @@ DEV double cand_toi(uint32_t s, double x1, double y1, double x2, double y2, doub
     return t;
 }
 
-// get_closest_point on a decoded candidate (entities.py:43-59,127-157)
-DEV bool cand_closest(uint32_t s, double x1, double y1, double x2, double y2, double px, double py, double &a, double &b) {
-    if ((s & 1u) == 0) {
-        int wxu = (int)((s >> 6) & 3) - (int)((s >> 2) & 3), wyu = (int)((s >> 8) & 3) - (int)((s >> 4) & 3);
-        double wx = 12.0 * wxu, wy = 12.0 * wyu;
-        double dx = px - x1, dy = py - y1;
-        int aw = wxu * wxu + wyu * wyu;
-        double num = dx * wx + dy * wy;
-        double u = aw == 1 ? div_const(num, 144.0, 1.0 / 144.0)
-                 : (aw == 8 ? div_const(num, 1152.0, 1.0 / 1152.0)
-                 : (aw == 5 ? div_const(num, 720.0, 1.0 / 720.0) : num / (sq(wx) + sq(wy))));
-        u = pymax(u, 0.0);
-        u = pymin(u, 1.0);
-        a = x1 + u * wx;
-        b = y1 + u * wy;
-        return dy * wx - dx * wy < 0;
-    }
+// GridSegmentCircular.get_closest_point on a decoded candidate (entities.py:127-157)
+DEV bool cand_closest_arc(uint32_t s, double x1, double y1, double x2, double y2, double px, double py,
+                                              double &a, double &b) {
     double hor = ((s >> 6) & 1) ? 1.0 : -1.0, ver = ((s >> 7) & 1) ? 1.0 : -1.0;
     bool convex = (s >> 8) & 1;
     double dx = px - x1, dy = py - y1;
@@ -539,9 +560,23 @@ DEV bool cand_closest(uint32_t s, double x1, double y1, double x2, double y2, do
     return back;
 }
 
+// GridSegmentLinear.get_closest_point (entities.py:43-59) on decoded registers, branch-free.  max/min are the
+// hardware ones: they differ from Python's max(u, 0) / min(u, 1) only in the sign of a zero u, which cannot reach
+// a or b (x1 + (+-0) * w == x1).
+template <int K> DEV bool cand_closest_lin(const Cand<K> &c, int k, double px, double py, double &a, double &b) {
+    double dx = px - c.x1[k], dy = py - c.y1[k];
+    double num = dx * c.wx[k] + dy * c.wy[k];
+    double u = div_const(num, c.l2[k], c.rl2[k]);
+    u = __builtin_fmax(u, 0.0);
+    u = __builtin_fmin(u, 1.0);
+    a = c.x1[k] + u * c.wx[k];
+    b = c.y1[k] + u * c.wy[k];
+    return dy * c.wx[k] - dx * c.wy[k] < 0;
+}
+
 // sweep_circle_vs_tiles (physics.py:104-128).  The early `return 0` of the reference equals the minimum.
 template <int G>
-__device__ __noinline__ double sweep_generic(const Lv &lv, int r, double xo, double yo, double dx, double dy, double radius) {
+__device__ __noinline__ double sweep_generic(TileRefs lv, int r, double xo, double yo, double dx, double dy, double radius) {
     double xn = xo + dx, yn = yo + dy;
     double width = radius + 1;
     double qx0 = (xo < xn ? xo : xn) - width, qy0 = (yo < yn ? yo : yn) - width;
@@ -562,29 +597,75 @@ __device__ __noinline__ double sweep_generic(const Lv &lv, int r, double xo, dou
     return group_min<G>(shortest);
 }
 
-// get_single_closest_point over the LDS tables (fallback of the register fast path)
-template <int G>
-__device__ __noinline__ void closest_generic(const Lv &lv, int r, const Query &qg, double gx0, double gy0, double gx1, double gy1,
-                                             double xpos, double ypos, Best &m) {
-    const double qx0 = xpos - NINJA_RADIUS, qy0 = ypos - NINJA_RADIUS, qx1 = xpos + NINJA_RADIUS, qy1 = ypos + NINJA_RADIUS;
-    int base = 0;
-    for (int xc = qg.c0x; xc <= qg.c1x; xc++) {
-        int i0 = lv.seg_start[xc * 25 + qg.c0y], i1 = lv.seg_start[xc * 25 + qg.c1y + 1];
-        for (int i = i0 + r; i < i1; i += G) {
-            uint32_t s = lv.segs[i];
-            int yc = s >> 11;
-            if (!cell_passes(lv.bounds[xc * 25 + yc], xc, yc, gx0, gy0, gx1, gy1)) continue;
-            double bx0, by0, bx1, by1;
-            seg_aabb(s, xc, yc, bx0, by0, bx1, by1);
-            if (bx1 < qx0 || bx0 > qx1 || by1 < qy0 || by0 > qy1) continue;
-            double a, b;
-            bool back = seg_closest(s, xc, yc, xpos, ypos, a, b);
-            double distance_sq = sq(xpos - a) + sq(ypos - b);
-            if (!back) distance_sq -= 0.1;
-            if (distance_sq < m.key) { m.key = distance_sq; m.a = a; m.b = b; m.idx = (base + i - i0) * 2 + (back ? 1 : 0); }
-        }
-        base += i1 - i0;
+// The depenetration loop of collide_vs_tiles (ninja.py:303-364) -- shared by the register fast path and the LDS
+// fallback.  CLOSEST(m) fills `m` with the lane's best candidate; everything else is identical.
+struct DepenIO {
+    double x, y, vx, vy, fnsx, fnsy, cnsx, cnsy;
+    int fcount, ccount, applied;
+};
+
+#define NPP_DEPEN_STEP(io, m, BREAK)                                                                   \
+    {                                                                                                  \
+        if ((m).idx == 0x7fffffff) BREAK; /* result == 0 */                                            \
+        const int result = ((m).idx & 1) ? -1 : 1;                                                     \
+        double ddx = (io).x - (m).a;                                                                   \
+        double ddy = (io).y - (m).b;                                                                   \
+        if (dabs(ddx) <= 0.0000001) { /* band-aid constants of the reference (ninja.py:313-318) */     \
+            ddx = 0;                                                                                   \
+            if ((io).x == 50.51197510492316 || (io).x == 49.23232124849253) ddx = -0x1p-47;            \
+            if ((io).x == 49.153536108584795) ddx = 0x1p-47;                                           \
+        }                                                                                              \
+        double dist_sq = ddx * ddx + ddy * ddy;                                                        \
+        if (dist_sq < 1e-16) BREAK;                                                                    \
+        double dist = dsqrt(dist_sq);                                                                  \
+        double depen_len = NINJA_RADIUS - dist * result;                                               \
+        if (depen_len < 0.0000001) BREAK;                                                              \
+        (io).applied = 1;                                                                              \
+        double inv_dist = 1.0 / dist;                                                                  \
+        double norm_dx = ddx * inv_dist, norm_dy = ddy * inv_dist;                                     \
+        (io).x += norm_dx * depen_len;                                                                 \
+        (io).y += norm_dy * depen_len;                                                                 \
+        double dot_product = (io).vx * ddx + (io).vy * ddy;                                            \
+        if (dot_product < 0) {                                                                         \
+            double cross_product = (io).vx * ddy - (io).vy * ddx;                                      \
+            double inv_dist_sq = inv_dist * inv_dist;                                                  \
+            (io).vx = cross_product * inv_dist_sq * ddy;                                               \
+            (io).vy = cross_product * inv_dist_sq * (-ddx);                                            \
+        }                                                                                              \
+        if (ddy >= -0.0001) { (io).ccount += 1; (io).cnsx += norm_dx; (io).cnsy += norm_dy; }          \
+        else { (io).fcount += 1; (io).fnsx += norm_dx; (io).fnsy += norm_dy; }                         \
     }
+
+// LDS-table fallback of the whole loop (rare: the query left the gathered region)
+template <int G>
+__device__ __noinline__ DepenIO depen_generic(TileRefs lv, int r, double gx0, double gy0, double gx1, double gy1, DepenIO io) {
+    const int c0x = cell_coord(gx0, 43), c1x = cell_coord(gx1, 43), c0y = cell_coord(gy0, 24), c1y = cell_coord(gy1, 24);
+    for (int it = 0; it < 32; it++) {
+        Best m;
+        m.key = __builtin_inf(); m.idx = 0x7fffffff; m.a = 0; m.b = 0;
+        const double qx0 = io.x - NINJA_RADIUS, qy0 = io.y - NINJA_RADIUS, qx1 = io.x + NINJA_RADIUS, qy1 = io.y + NINJA_RADIUS;
+        int base = 0;
+        for (int xc = c0x; xc <= c1x; xc++) {
+            int i0 = lv.seg_start[xc * 25 + c0y], i1 = lv.seg_start[xc * 25 + c1y + 1];
+            for (int i = i0 + r; i < i1; i += G) {
+                uint32_t s = lv.segs[i];
+                int yc = s >> 11;
+                if (!cell_passes(lv.bounds[xc * 25 + yc], xc, yc, gx0, gy0, gx1, gy1)) continue;
+                double bx0, by0, bx1, by1;
+                seg_aabb(s, xc, yc, bx0, by0, bx1, by1);
+                if (bx1 < qx0 || bx0 > qx1 || by1 < qy0 || by0 > qy1) continue;
+                double a, b;
+                bool back = seg_closest(s, xc, yc, io.x, io.y, a, b);
+                double distance_sq = sq(io.x - a) + sq(io.y - b);
+                if (!back) distance_sq -= 0.1;
+                if (distance_sq < m.key) { m.key = distance_sq; m.a = a; m.b = b; m.idx = (base + i - i0) * 2 + (back ? 1 : 0); }
+            }
+            base += i1 - i0;
+        }
+        group_argmin<G>(m);
+        NPP_DEPEN_STEP(io, m, break)
+    }
+    return io;
 }
 
 // Ninja.collide_vs_tiles (ninja.py:269-379).  Returns true when at least one depenetration was applied.
@@ -593,25 +674,30 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
                           double &cnsx, double &cnsy STAMP_ARG) {
     double dx = n.x - xold, dy = n.y - yold;
     // ---- sweep_circle_vs_tiles (physics.py:104-128); the early `return 0` of the reference equals the minimum
-    double time;
+    double time = 1;
     {
         const double radius = NINJA_RADIUS * 0.5, width = radius + 1;
         double xn = xold + dx, yn = yold + dy;
-        double qx0 = (xold < xn ? xold : xn) - width, qy0 = (yold < yn ? yold : yn) - width;
-        double qx1 = (xold > xn ? xold : xn) + width, qy1 = (yold > yn ? yold : yn) + width;
-        Query q = make_query(qx0, qy0, qx1, qy1);
+        const QBox q = make_qbox((xold < xn ? xold : xn) - width, (yold < yn ? yold : yn) - width,
+                                 (xold > xn ? xold : xn) + width, (yold > yn ? yold : yn) + width);
         if (cand_covers(cd, q)) {
-            double vel_sq = sq(dx) + sq(dy);
-            double shortest = 1;
+            bool in[K];
+            bool any = false;
 #pragma unroll
-            for (int k = 0; k < K; k++)
-                if (cand_in_query(cd.s[k], cd.babs[k], q)) {
-                    double t = cand_toi(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], xold, yold, dx, dy, vel_sq, radius);
-                    if (t < shortest) shortest = t;
-                }
-            time = group_min<G>(shortest);
+            for (int k = 0; k < K; k++) { in[k] = cand_in_box(cd, k, q); any |= in[k]; }
+            if (group_any<G>(any)) {   // most sweeps touch no segment at all
+                double vel_sq = sq(dx) + sq(dy);
+                double shortest = 1;
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (in[k]) {
+                        double t = cand_toi(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], xold, yold, dx, dy, vel_sq, radius);
+                        if (t < shortest) shortest = t;
+                    }
+                time = group_min<G>(shortest);
+            }
         } else {
-            time = sweep_generic<G>(lv, r, xold, yold, dx, dy, radius);
+            time = sweep_generic<G>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, xold, yold, dx, dy, radius);
         }
     }
     n.x = xold + time * dx;
@@ -619,72 +705,56 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
     // the segment list is gathered ONCE at the post-sweep position (ninja.py:282-285): the cell filter keeps using
     // this box for all iterations, the per-segment AABB test uses the moving position (physics.py:150-167)
     const double gx0 = n.x - NINJA_RADIUS, gy0 = n.y - NINJA_RADIUS, gx1 = n.x + NINJA_RADIUS, gy1 = n.y + NINJA_RADIUS;
-    const Query qg = make_query(gx0, gy0, gx1, gy1);
+    const QBox qg = make_qbox(gx0, gy0, gx1, gy1);
     const bool fast = cand_covers(cd, qg);
     uint32_t gp = 0;
     if (fast) {
 #pragma unroll
-        for (int k = 0; k < K; k++) gp |= cand_in_query(cd.s[k], cd.babs[k], qg) ? (1u << k) : 0u;
+        for (int k = 0; k < K; k++) gp |= cand_in_box(cd, k, qg) ? (1u << k) : 0u;
+        if (!group_any<G>(gp != 0)) return false;   // empty list: result == 0 at the first iteration
     }
-    double xpos = n.x, ypos = n.y, xspeed = n.vx, yspeed = n.vy;
-    bool applied = false;
+    DepenIO io;
+    io.x = n.x; io.y = n.y; io.vx = n.vx; io.vy = n.vy;
+    io.fnsx = fnsx; io.fnsy = fnsy; io.cnsx = cnsx; io.cnsy = cnsy;
+    io.fcount = n.fcount; io.ccount = n.ccount; io.applied = 0;
     STAMP(9);   // sweep + gather setup
-    for (int it = 0; it < 32; it++) {
+    if (fast) {
+        for (int it = 0; it < 32; it++) {
 #ifdef NPP_STAMPS
-        st.acc[fast ? 10 : 11] += 1;   // iteration counts (fast / LDS fallback)
+            st.acc[10] += 1;   // iteration count (register fast path)
 #endif
-        // get_single_closest_point (physics.py:131-180)
-        Best m;
-        m.key = __builtin_inf(); m.idx = 0x7fffffff; m.a = 0; m.b = 0;
-        const double qx0 = xpos - NINJA_RADIUS, qy0 = ypos - NINJA_RADIUS, qx1 = xpos + NINJA_RADIUS, qy1 = ypos + NINJA_RADIUS;
-        if (fast) {
+            // get_single_closest_point (physics.py:131-180) over the candidate registers
+            Best m;
+            m.key = __builtin_inf(); m.idx = 0x7fffffff; m.a = 0; m.b = 0;
+            const double qx0 = io.x - NINJA_RADIUS, qy0 = io.y - NINJA_RADIUS, qx1 = io.x + NINJA_RADIUS, qy1 = io.y + NINJA_RADIUS;
 #pragma unroll
             for (int k = 0; k < K; k++)
                 if ((gp >> k) & 1u) {
-                    double bx0 = cd.x1[k] < cd.x2[k] ? cd.x1[k] : cd.x2[k], bx1 = cd.x1[k] < cd.x2[k] ? cd.x2[k] : cd.x1[k];
-                    double by0 = cd.y1[k] < cd.y2[k] ? cd.y1[k] : cd.y2[k], by1 = cd.y1[k] < cd.y2[k] ? cd.y2[k] : cd.y1[k];
-                    if (bx1 < qx0 || bx0 > qx1 || by1 < qy0 || by0 > qy1) continue;
+                    double bx0 = __builtin_fmin(cd.x1[k], cd.x2[k]), bx1 = __builtin_fmax(cd.x1[k], cd.x2[k]);
+                    double by0 = __builtin_fmin(cd.y1[k], cd.y2[k]), by1 = __builtin_fmax(cd.y1[k], cd.y2[k]);
+                    bool in = !((bx1 < qx0) | (bx0 > qx1) | (by1 < qy0) | (by0 > qy1));
                     double a, b;
-                    bool back = cand_closest(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], xpos, ypos, a, b);
-                    double distance_sq = sq(xpos - a) + sq(ypos - b);
-                    if (!back) distance_sq -= 0.1;
-                    if (distance_sq < m.key) { m.key = distance_sq; m.a = a; m.b = b; m.idx = (k * G + r) * 2 + (back ? 1 : 0); }
+                    bool back = cand_closest_lin(cd, k, io.x, io.y, a, b);
+                    if (in & ((cd.s[k] & 1u) != 0)) back = cand_closest_arc(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], io.x, io.y, a, b);
+                    double distance_sq = sq(io.x - a) + sq(io.y - b);
+                    double key = back ? distance_sq : distance_sq - 0.1;
+                    bool take = in & (key < m.key);
+                    m.key = take ? key : m.key; m.a = take ? a : m.a; m.b = take ? b : m.b;
+                    m.idx = take ? (k * G + r) * 2 + (back ? 1 : 0) : m.idx;
                 }
-        } else {
-            closest_generic<G>(lv, r, qg, gx0, gy0, gx1, gy1, xpos, ypos, m);
+            group_argmin<G>(m);
+            NPP_DEPEN_STEP(io, m, break)
         }
-        group_argmin<G>(m);
-        if (m.idx == 0x7fffffff) break;   // result == 0
-        const int result = (m.idx & 1) ? -1 : 1;
-        dx = xpos - m.a;
-        dy = ypos - m.b;
-        if (dabs(dx) <= 0.0000001) {   // band-aid constants of the reference (ninja.py:313-318)
-            dx = 0;
-            if (xpos == 50.51197510492316 || xpos == 49.23232124849253) dx = -0x1p-47;
-            if (xpos == 49.153536108584795) dx = 0x1p-47;
-        }
-        double dist_sq = dx * dx + dy * dy;
-        if (dist_sq < 1e-16) break;
-        double dist = dsqrt(dist_sq);
-        double depen_len = NINJA_RADIUS - dist * result;
-        if (depen_len < 0.0000001) break;
-        applied = true;
-        double inv_dist = 1.0 / dist;
-        double norm_dx = dx * inv_dist, norm_dy = dy * inv_dist;
-        xpos += norm_dx * depen_len;
-        ypos += norm_dy * depen_len;
-        double dot_product = xspeed * dx + yspeed * dy;
-        if (dot_product < 0) {
-            double cross_product = xspeed * dy - yspeed * dx;
-            double inv_dist_sq = inv_dist * inv_dist;
-            xspeed = cross_product * inv_dist_sq * dy;
-            yspeed = cross_product * inv_dist_sq * (-dx);
-        }
-        if (dy >= -0.0001) { n.ccount += 1; cnsx += norm_dx; cnsy += norm_dy; }
-        else { n.fcount += 1; fnsx += norm_dx; fnsy += norm_dy; }
+    } else {
+#ifdef NPP_STAMPS
+        st.acc[11] += 1;   // substeps that took the LDS fallback
+#endif
+        io = depen_generic<G>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, gx0, gy0, gx1, gy1, io);
     }
-    n.x = xpos; n.y = ypos; n.vx = xspeed; n.vy = yspeed;
-    return applied;
+    n.x = io.x; n.y = io.y; n.vx = io.vx; n.vy = io.vy;
+    fnsx = io.fnsx; fnsy = io.fnsy; cnsx = io.cnsx; cnsy = io.cnsy;
+    n.fcount = io.fcount; n.ccount = io.ccount;
+    return io.applied != 0;
 }
 
 // overlap_circle_vs_circle (physics.py:204-207) with an exact-safe early reject
@@ -708,10 +778,10 @@ DEV double mine_radius(uint32_t st) { return st == 0 ? 4.0 : (st == 1 ? 3.5 : 4.
 // (overlap radius <= 14.5 px < 24 px), and visiting a superset is harmless, so the bounding box of the two 3x3
 // neighbourhoods is scanned.  (All lanes of a group run this redundantly and write identical LDS words.)
 DEV void think_mines(const Lv &lv, Nj &n, EntBits eb) {
+    if (lv.n_think == 0) return;   // pcell is only read here, so it needs no upkeep on mine-free levels
     int ccx = cell_coord(n.x, 43), ccy = cell_coord(n.y, 24);
     int pcx = n.pcell / 25, pcy = n.pcell - pcx * 25;
     n.pcell = ccx * 25 + ccy;
-    if (lv.n_think == 0) return;
     bool vt = valid_target(n.state);
     if (!vt && n.state != 6) return;
     int x0 = (ccx < pcx ? ccx : pcx) - 1, x1 = (ccx > pcx ? ccx : pcx) + 1;
@@ -797,12 +867,13 @@ DEV double wall_term(double px, double py, double a, double b, double rad) {
 }
 
 template <int G>
-__device__ __noinline__ double wall_probe_generic(const Lv &lv, int r, const Query &q, double px, double py, double qx0, double qy0,
+__device__ __noinline__ double wall_probe_generic(TileRefs lv, int r, double px, double py, double qx0, double qy0,
                                                   double qx1, double qy1) {
     const double rad = NINJA_RADIUS + 0.1;
+    const int c0x = cell_coord(qx0, 43), c1x = cell_coord(qx1, 43), c0y = cell_coord(qy0, 24), c1y = cell_coord(qy1, 24);
     double wall_normal = 0;
-    for (int xc = q.c0x; xc <= q.c1x; xc++) {
-        int i0 = lv.seg_start[xc * 25 + q.c0y], i1 = lv.seg_start[xc * 25 + q.c1y + 1];
+    for (int xc = c0x; xc <= c1x; xc++) {
+        int i0 = lv.seg_start[xc * 25 + c0y], i1 = lv.seg_start[xc * 25 + c1y + 1];
         for (int ib = i0; ib < i1; ib += G) {   // group-uniform trip count
             int i = ib + r;
             double term = 0;
@@ -829,20 +900,21 @@ DEV void post_collision(const Lv &lv, int r, Nj &n, const Cand<K> &cd, EntBits e
     double wall_normal = 0;
     const double rad = NINJA_RADIUS + 0.1;
     double qx0 = n.x - rad, qy0 = n.y - rad, qx1 = n.x + rad, qy1 = n.y + rad;
-    const Query q = make_query(qx0, qy0, qx1, qy1);
+    const QBox q = make_qbox(qx0, qy0, qx1, qy1);
     if (cand_covers(cd, q)) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             double term = 0;
-            if (cand_in_query(cd.s[k], cd.babs[k], q)) {
+            if (cand_in_box(cd, k, q)) {
                 double a, b;
-                cand_closest(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], n.x, n.y, a, b);
+                if ((cd.s[k] & 1u) == 0) cand_closest_lin(cd, k, n.x, n.y, a, b);
+                else cand_closest_arc(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], n.x, n.y, a, b);
                 term = wall_term(n.x, n.y, a, b, rad);
             }
-            ordered_add<G>(wall_normal, term);
+            if (group_any<G>(term != 0)) ordered_add<G>(wall_normal, term);
         }
     } else {
-        wall_normal = wall_probe_generic<G>(lv, r, q, n.x, n.y, qx0, qy0, qx1, qy1);
+        wall_normal = wall_probe_generic<G>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, n.x, n.y, qx0, qy0, qx1, qy1);
     }
     n.airborn_old = n.airborn;
     n.airborn = 1;
@@ -1053,7 +1125,7 @@ DEV void sim_tick(const Lv &lv, int r, Nj &n, EntBits eb, int hor, int jump STAM
 
 // ---- observations ---------------------------------------------------------------------------------------------
 // get_ninja_state (nplay_headless.py:735-924) + time_remaining (base_environment.py:2811-2829); fp64 then f32 cast
-__device__ __noinline__ void write_game_state(const Nj &n, int limit, float *o /* stride 1 */) {
+DEV void write_game_state(const Nj &n, int limit, float *o /* stride 1 */) {
     double vmag = dsqrt(sq(n.vx) + sq(n.vy));
     o[0] = (float)(pymin(vmag / (MAX_HOR_SPEED * 2), 1.0) * 2 - 1);
     bool mv = vmag > 1e-6;
@@ -1238,18 +1310,28 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     }
 
     const bool do_reset = a.autoreset && stepping && done;
-    if (a.out.terminal_state && do_reset && writer) write_game_state(n, limit, a.out.terminal_state + (size_t)env * 41);
-    if (do_reset) {
-        spawn_state(lv, n);
-        for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
-    }
-
-    // observations, assembled in LDS then stored as contiguous workgroup writes
-    if (a.out.game_state) {
-        if (r == 0) write_game_state(n, limit, reinterpret_cast<float *>(stage) + eib * 41);
-        __syncthreads();
-        block_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.game_state + (size_t)env0 * 41), 41, n_valid);
-        __syncthreads();
+    // game_state rows are assembled in LDS and stored as contiguous workgroup writes.  Pass 0 (only when a
+    // terminal-observation buffer was given) writes the pre-reset state of the envs that are being reset; pass 1
+    // resets those envs and writes the observation every env returns.
+#pragma nounroll
+    for (int pass = (a.out.terminal_state ? 0 : 1); pass < 2; pass++) {
+        if (pass == 1 && do_reset) {
+            spawn_state(lv, n);
+            for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
+        }
+        float *gdst = pass == 0 ? a.out.terminal_state : a.out.game_state;
+        if (gdst) {
+            if (r == 0) write_game_state(n, limit, reinterpret_cast<float *>(stage) + eib * 41);
+            __syncthreads();
+            if (pass == 1) {
+                block_store_rows(stage, reinterpret_cast<uint32_t *>(gdst + (size_t)env0 * 41), 41, n_valid);
+            } else if (do_reset && writer) {
+                const uint32_t *row = stage + eib * 41;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(gdst + (size_t)env * 41);
+                for (int k = 0; k < 41; k++) dst[k] = row[k];
+            }
+            __syncthreads();
+        }
     }
     if (a.out.entity_pos) {
         if (r == 0) {
