@@ -382,18 +382,35 @@ template <int G, int STEP = 1> DEV double group_min(double t) {
 
 struct Best {
     double key;   // biased squared distance (physics.py:171-176)
-    int idx;      // flat query index * 2 + is_back_facing
+    int idx;      // flat query index << 8 | evaluating lane's rank in its group << 1 | is_back_facing
     double a, b;  // closest point
 };
 
-template <int G, int STEP = 1> DEV void group_argmin(Best &m) {
+template <int G, int STEP = 1> DEV int group_min_i(int v) {
     if constexpr (STEP < G) {
-        double k = partner_d<STEP>(m.key);
-        int i = partner_i<STEP>(m.idx);
-        double a = partner_d<STEP>(m.a), b = partner_d<STEP>(m.b);
-        bool take = (k < m.key) || (k == m.key && i < m.idx);
-        m.key = take ? k : m.key; m.idx = take ? i : m.idx; m.a = take ? a : m.a; m.b = take ? b : m.b;
-        group_argmin<G, STEP * 2>(m);
+        int o = partner_i<STEP>(v);
+        v = o < v ? o : v;
+        return group_min_i<G, STEP * 2>(v);
+    } else {
+        return v;
+    }
+}
+
+// Group-wide "first wins" argmin (physics.py:176 strict <): smallest key, ties broken by the smallest flat query
+// index.  Two cheap butterflies (key, then index among the lanes holding the minimum key) and one cross-lane fetch
+// of the winner's closest point; every lane of the group ends up with the same m.
+template <int G> DEV void group_argmin(Best &m) {
+    if constexpr (G > 1) {
+        const double kmin = group_min<G>(m.key);
+        const int cand = (m.idx != 0x7fffffff && m.key == kmin) ? m.idx : 0x7fffffff;
+        const int imin = group_min_i<G>(cand);
+        const int src = (((threadIdx.x & 63) & ~(G - 1)) + ((imin >> 1) & 63)) << 2;   // winner lane, byte address
+        int alo = __builtin_amdgcn_ds_bpermute(src, __double2loint(m.a)), ahi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(m.a));
+        int blo = __builtin_amdgcn_ds_bpermute(src, __double2loint(m.b)), bhi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(m.b));
+        m.key = kmin;
+        m.idx = imin;
+        m.a = __hiloint2double(ahi, alo);
+        m.b = __hiloint2double(bhi, blo);
     }
 }
 
@@ -658,7 +675,7 @@ __device__ __noinline__ DepenIO depen_generic(TileRefs lv, int r, double gx0, do
                 bool back = seg_closest(s, xc, yc, io.x, io.y, a, b);
                 double distance_sq = sq(io.x - a) + sq(io.y - b);
                 if (!back) distance_sq -= 0.1;
-                if (distance_sq < m.key) { m.key = distance_sq; m.a = a; m.b = b; m.idx = (base + i - i0) * 2 + (back ? 1 : 0); }
+                if (distance_sq < m.key) { m.key = distance_sq; m.a = a; m.b = b; m.idx = ((base + i - i0) << 8) | (r << 1) | (back ? 1 : 0); }
             }
             base += i1 - i0;
         }
@@ -740,7 +757,7 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
                     double key = back ? distance_sq : distance_sq - 0.1;
                     bool take = in & (key < m.key);
                     m.key = take ? key : m.key; m.a = take ? a : m.a; m.b = take ? b : m.b;
-                    m.idx = take ? (k * G + r) * 2 + (back ? 1 : 0) : m.idx;
+                    m.idx = take ? (((k * G + r) << 8) | (r << 1) | (back ? 1 : 0)) : m.idx;
                 }
             group_argmin<G>(m);
             NPP_DEPEN_STEP(io, m, break)
