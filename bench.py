@@ -34,6 +34,24 @@ ALGO_BYTES_PER_ENV_STEP = 522
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def committed_traffic():
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
+    gfx950 x2 correction on FETCH_SIZE) of this same command; tools/profile_round.sh collects them and
+    tools/summarize_profiles.py writes profiles/<round>_summary.json.  bench.py cannot run PMC passes on itself, so
+    it reports the newest committed figure (or null)."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            t = json.load(open(f)).get("traffic", {}).get("hbm_bytes_per_launch")
+            if t:
+                best = (float(t), os.path.basename(f))
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(levels, seconds_target=12.0):
     """Time the CPU oracle ("port": C restatement of the reference tick, bit-checked against reference
     fixtures) on this box's host cores with OpenMP, on a bounded sample of the same workload."""
@@ -175,7 +193,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": (committed_traffic() or (None, None))[0],
+                "traffic_source": (committed_traffic() or (None, None))[1],
                 "kernel": "npp_step_kernel",
                 "avg_launch_us": launch_us,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,

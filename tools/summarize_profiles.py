@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) into small files under
+profiles/: kernel stats CSV rows for our kernels, HBM traffic per launch (FETCH_SIZE / WRITE_SIZE with the
+gfx950 corrections of MI355X_MICROARCH.md "HBM"), SQ counter means."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def counter_means(path, kernel="npp_step_kernel"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Kernel_Name"]:
+            agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {c: {"dispatches": len(d), "mean_per_dispatch": sum(d.values()) / len(d)} for c, d in agg.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    out = {"tag": tag}
+    ks = find(os.path.join(src, "trace"), "*kernel_stats.csv")
+    if ks:
+        rows = [r for r in csv.DictReader(open(ks)) if "npp_" in r["Name"]]
+        with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+        for r in rows:
+            if "npp_step_kernel" in r["Name"]:
+                out["step_kernel"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                      "max_ns": float(r["MaxNs"])}
+    kt = find(os.path.join(src, "trace"), "*kernel_trace.csv")
+    if kt and "step_kernel" in out:
+        # the bench's timed region = the LAST `steps` dispatches of the step kernel (warm-up launches come first)
+        rows = [r for r in csv.DictReader(open(kt)) if "npp_step_kernel" in r["Kernel_Name"]]
+        steps = 300
+        try:
+            steps = json.loads(open(os.path.join(src, "bench_line.json")).read())["steps"]
+        except Exception:
+            pass
+        last = rows[-steps:]
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
+        out["step_kernel"]["timed_region_avg_ns"] = sum(d) / len(d)
+        out["step_kernel"]["timed_region_launches"] = len(d)
+        out["step_kernel"]["grid_size"] = last[0].get("Grid_Size")
+        out["step_kernel"]["workgroup_size"] = last[0].get("Workgroup_Size")
+        out["step_kernel"]["vgpr"] = last[0].get("VGPR_Count")
+        out["step_kernel"]["lds_block_size"] = last[0].get("LDS_Block_Size")
+    traffic = {}
+    for name in ("fetch", "write"):
+        cc = find(os.path.join(src, name), "*counter_collection.csv")
+        if cc:
+            traffic.update(counter_means(cc))
+    if traffic:
+        # FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B (hbm_bytes = value * 1024); on gfx950
+        # FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams (x2 correction).  This kernel's reads
+        # are 8-byte-per-lane plane reads (uncalibrated width), so both the raw and the x2 figure are recorded.
+        fs = traffic.get("FETCH_SIZE", {}).get("mean_per_dispatch")
+        ws = traffic.get("WRITE_SIZE", {}).get("mean_per_dispatch")
+        out["traffic"] = {
+            "FETCH_SIZE_mean": fs, "WRITE_SIZE_mean": ws,
+            "read_bytes_per_launch_raw": None if fs is None else fs * 1024,
+            "read_bytes_per_launch_x2": None if fs is None else fs * 2048,
+            "write_bytes_per_launch": None if ws is None else ws * 1024,
+        }
+        if fs is not None and ws is not None:
+            out["traffic"]["hbm_bytes_per_launch"] = fs * 2048 + ws * 1024
+    sq = find(os.path.join(src, "sq"), "*counter_collection.csv")
+    if sq:
+        out["sq"] = counter_means(sq)
+    bl = os.path.join(src, "bench_line.json")
+    if os.path.isfile(bl) and os.path.getsize(bl):
+        out["bench_line_under_profiler"] = json.loads(open(bl).read())
+    with open(os.path.join(dst, "%s_summary.json" % tag), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
