@@ -1,0 +1,115 @@
+"""Parity at BASELINE.json's full sizes (8192 envs): properties that do not need the oracle to run 8192 envs --
+(1) replicas: envs that share a level and an action stream must hold identical bits, whatever wavefront they sit in;
+(2) geometry invariance: G = 16 (shipped) vs G = 1 (one lane per env) on the whole batch;
+(3) a random sample of envs is re-simulated by the CPU oracle with the same actions and compared bit-for-bit
+    (fp64 state, discrete fields, entity states) -- configs 2 (exit+switch), 3 (mines) and 5 (locked doors);
+(4) determinism: the same launch sequence twice gives the same bits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N = 8192
+
+
+def _run(levels, level_ids, acts, g=None, steps=None, autoreset=True):
+    from nclone_amd.engine import NppBatch
+
+    b = NppBatch(N, autoreset=autoreset)
+    b.load_levels(levels)
+    if g is not None:
+        b.set_launch_geometry(g, 0)
+    b.assign_levels(level_ids)
+    steps = len(acts) if steps is None else steps
+    hist = []
+    for s in range(steps):
+        b.step(acts[s])
+        hist.append(b.flags.clone())
+    f, i = b.dump_state()
+    return b, f, i, torch.stack(hist).cpu().numpy()
+
+
+@pytest.mark.parametrize("which", ["c0", "mines", "doors"])
+def test_full_size_sample_vs_oracle(which, oracle_mod):
+    from nclone_amd.levels import curriculum0_levels, door_levels, mine_levels
+
+    levels, _ = {"c0": curriculum0_levels, "mines": mine_levels, "doors": door_levels}[which]()
+    level_ids = (np.arange(N) // 64) % len(levels)
+    steps = 60
+    rng = np.random.default_rng({"c0": 0, "mines": 1, "doors": 3}[which])
+    acts_np = rng.integers(0, 6, size=(steps, N)).astype(np.uint8)
+    # replicas: the second half of every 64-env block repeats the first half's actions
+    acts_np = acts_np.reshape(steps, N // 64, 64)
+    acts_np[:, :, 32:] = acts_np[:, :, :32]
+    acts_np = acts_np.reshape(steps, N)
+    acts = torch.from_numpy(acts_np).cuda()
+    b, f, i, flags = _run(levels, level_ids, acts)
+    # (1) replicas
+    fb, ib = f.reshape(N // 64, 64, -1), i.reshape(N // 64, 64, -1)
+    assert np.array_equal(fb[:, :32], fb[:, 32:]) and np.array_equal(ib[:, :32, :27], ib[:, 32:, :27])
+    # (3) oracle on a sample (auto-reset semantics: reset when the step ended terminal or truncated)
+    sample = np.random.default_rng(99).choice(N, size=192, replace=False)
+    worst_frames = 0
+    for e in sample:
+        o = oracle_mod.Oracle("mul")
+        assert o.load(levels[level_ids[e]]) == 0
+        for s in range(steps):
+            k, fl = o.env_step(int(acts_np[s, e]), 4)
+            got = int(flags[s, e])
+            assert (1 if got & 1 else (2 if got & 2 else 0)) == fl, (which, e, s)
+            if fl or o.frame >= 10000:
+                o.reset()
+        of, od = o.core()
+        assert np.array_equal(f[e], of), (which, e, f[e], of)
+        assert np.array_equal(i[e, :22], od[:22]), (which, e)
+        assert np.array_equal(b.dump_entities(int(e)), o.entity_states()), (which, e)
+        worst_frames = max(worst_frames, o.frame)
+    # the runs must actually exercise terminations
+    assert (flags & 3).any()
+    # (2) geometry invariance and (4) determinism on the full batch
+    _, f1, i1, fl1 = _run(levels, level_ids, acts, g=1, steps=20)
+    _, f16, i16, fl16 = _run(levels, level_ids, acts, g=16, steps=20)
+    _, f16b, i16b, fl16b = _run(levels, level_ids, acts, g=16, steps=20)
+    assert np.array_equal(f1, f16) and np.array_equal(i1, i16) and np.array_equal(fl1, fl16)
+    assert np.array_equal(f16, f16b) and np.array_equal(i16, i16b)
+
+
+def test_truncation_and_terminal_envs_stay_put():
+    """Truncation at the frame limit (truncation_checker.py:46-77) with auto-reset; without auto-reset a terminal env
+    is not stepped again (frames executed 0) until reset."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import curriculum0_levels
+
+    levels, _ = curriculum0_levels()
+    n = 256
+    b = NppBatch(n, autoreset=True)
+    b.load_levels(levels[:4])
+    b.assign_levels((np.arange(n) // 64) % 4)
+    b.set_truncation_limit(40)
+    acts = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    for s in range(10):
+        b.step(acts)
+        fl = b.flags.cpu().numpy()
+        _, i = b.dump_state()
+        if s < 9:
+            assert not (fl & 8).any() and (i[:, 22] == 4 * (s + 1)).all()
+        else:
+            assert ((fl & 8) != 0).all() and (i[:, 22] == 0).all()   # truncated at frame 40 and reset
+    gs = b.game_state.cpu().numpy()
+    assert np.allclose(gs[:, 40], 1.0)
+    b2 = NppBatch(n, autoreset=False)
+    b2.load_levels(levels[:4])
+    b2.assign_levels((np.arange(n) // 64) % 4)
+    right = torch.full((n,), 2, dtype=torch.uint8, device="cuda")
+    done_at = {}
+    for s in range(200):
+        b2.step(right)
+        fl = b2.flags.cpu().numpy()
+        fr = b2.frames.cpu().numpy()
+        for e in np.nonzero(fl & 3)[0]:
+            if e in done_at:
+                assert fr[e] == 0
+            else:
+                done_at[e] = s
+    assert len(done_at) > 0
