@@ -347,7 +347,9 @@ DEV void seg_aabb(uint32_t s, int xc, int yc, double &x0, double &y0, double &x1
 // with DPP butterflies.  Order-dependent semantics of the reference are preserved exactly: minima are
 // order-independent, "first wins" ties (physics.py:176 strict <) are broken by the flat query index, and the wall
 // probe's sum (ninja.py:441) is accumulated in query order.
-template <int CTRL> DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// The butterfly partner always lies in the same lane group, whose lanes execute together, so it is always active:
+// bound_ctrl lets the compiler fold the move into the consuming instruction instead of keeping a copy for `old`.
+template <int CTRL> DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL> DEV double dpp_d(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = dpp_i<CTRL>(lo);
@@ -372,8 +374,7 @@ template <int STEP> DEV double partner_d(double v) {
 
 template <int G, int STEP = 1> DEV double group_min(double t) {
     if constexpr (STEP < G) {
-        double o = partner_d<STEP>(t);
-        if (o < t) t = o;
+        t = __builtin_fmin(t, partner_d<STEP>(t));   // operands are never NaN (+inf / 1 mark "none")
         return group_min<G, STEP * 2>(t);
     } else {
         return t;
@@ -614,6 +615,32 @@ __device__ __noinline__ double sweep_generic(TileRefs lv, int r, double xo, doub
     return group_min<G>(shortest);
 }
 
+// sqrt(x) and 1/x for operands that are known to be normal and far from the exponent limits (1e-16 <= x <= 1e8):
+// exactly the instruction sequences hipcc emits for IEEE f64 sqrt and division (v_rsq / v_rcp seed, Newton-Raphson
+// in fma, final residual correction) WITHOUT the v_ldexp range scaling, v_div_scale and v_cmp_class / v_div_fixup
+// special-case handling, which are identities in this range -- so the results are the same bits.
+DEV double sqrt_inrange(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+DEV double rcp_inrange(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double rem = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(rem, y, y);
+}
+
 // The depenetration loop of collide_vs_tiles (ninja.py:303-364) -- shared by the register fast path and the LDS
 // fallback.  CLOSEST(m) fills `m` with the lane's best candidate; everything else is identical.
 struct DepenIO {
@@ -634,11 +661,11 @@ struct DepenIO {
         }                                                                                              \
         double dist_sq = ddx * ddx + ddy * ddy;                                                        \
         if (dist_sq < 1e-16) BREAK;                                                                    \
-        double dist = dsqrt(dist_sq);                                                                  \
+        double dist = sqrt_inrange(dist_sq); /* 1e-16 <= dist_sq */                                    \
         double depen_len = NINJA_RADIUS - dist * result;                                               \
         if (depen_len < 0.0000001) BREAK;                                                              \
         (io).applied = 1;                                                                              \
-        double inv_dist = 1.0 / dist;                                                                  \
+        double inv_dist = rcp_inrange(dist);                                                           \
         double norm_dx = ddx * inv_dist, norm_dy = ddy * inv_dist;                                     \
         (io).x += norm_dx * depen_len;                                                                 \
         (io).y += norm_dy * depen_len;                                                                 \
