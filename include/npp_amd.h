@@ -61,6 +61,7 @@ enum {
 #define NPP_GAME_STATE_DIM 41   /* gym_environment/constants.py:25 */
 #define NPP_ACTION_DIM 6        /* base_environment.py:150 Discrete(6) */
 #define NPP_ENTITY_POS_DIM 6    /* observation_processor.py:340-361 */
+#define NPP_SPATIAL_CONTEXT_DIM 112 /* gym_environment/constants.py SPATIAL_CONTEXT_DIM */
 #define NPP_FRAME_W 84          /* gym_environment/constants.py:12-13 */
 #define NPP_FRAME_H 84
 #define NPP_DUMP_F64 12
@@ -77,6 +78,9 @@ typedef struct {
     uint16_t *d_frames;       /* [N]    u16: ticks executed this step (info["frame_skip_stats"]) */
     float *d_terminal_state;  /* [N,41] f32: game_state of the terminal state for envs that were
                                  auto-reset this step (rows of other envs are left untouched) */
+    float *d_spatial_context; /* [N,112] f32: 8x8 local tile categories + 8 nearest mines x 6 features
+                                 (gym_environment/spatial_context.py:113-176,309-508 as called from
+                                 npp_environment.py:2318-2360, incl. its >= 12 px position cache) */
 } npp_step_out;
 
 /* Simulator()+NPlayHeadless() for n_envs environments on GPU device_id. */

@@ -37,6 +37,7 @@ class StepOut(C.Structure):
         ("d_reward", C.c_void_p),
         ("d_frames", C.c_void_p),
         ("d_terminal_state", C.c_void_p),
+        ("d_spatial_context", C.c_void_p),
     ]
 
 

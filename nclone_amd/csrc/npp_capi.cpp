@@ -21,6 +21,7 @@ struct npp_handle_s {
     double *d_f64 = nullptr;
     uint32_t *d_u32 = nullptr;
     uint32_t *d_ent = nullptr;
+    float *d_sc_cache = nullptr;
     int32_t *d_env_level = nullptr;
     int32_t *d_trunc = nullptr;
     uint8_t *d_mask = nullptr;
@@ -108,6 +109,7 @@ KernelArgs base_args(npp_handle h) {
     a.f64 = h->d_f64;
     a.u32 = h->d_u32;
     a.ent_bits = h->d_ent;
+    a.sc_cache = h->d_sc_cache;
     a.env_level = h->d_env_level;
     a.trunc_limit = h->d_trunc;
     a.hdr = h->d_hdr;
@@ -131,6 +133,7 @@ void fill_out(KernelArgs &a, const npp_step_out *o) {
     a.out.reward = o->d_reward;
     a.out.frames = o->d_frames;
     a.out.terminal_state = o->d_terminal_state;
+    a.out.spatial_context = o->d_spatial_context;
 }
 
 }  // namespace
@@ -157,7 +160,8 @@ int npp_create(int n_envs, int device_id, unsigned flags, npp_handle *out) {
     hipError_t e3 = hipMalloc((void **)&h->d_env_level, sizeof(int32_t) * N);
     hipError_t e4 = hipMalloc((void **)&h->d_trunc, sizeof(int32_t) * N);
     hipError_t e5 = hipMalloc((void **)&h->d_mask, N);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+    hipError_t e6 = hipMalloc((void **)&h->d_sc_cache, sizeof(float) * 48 * N);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) {
         npp_destroy(h);
         return fail(nullptr, NPP_ERR_HIP, "npp_create: hipMalloc failed");
     }
@@ -174,7 +178,7 @@ int npp_destroy(npp_handle h) {
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
-    hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr);
+    hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache);
     delete h;
     return NPP_OK;
 }

@@ -7,7 +7,7 @@
 namespace npp {
 
 // ---- SoA ninja state: f64 plane k of env e lives at d_f64[k * n_envs + e] (coalesced per wave) -------------------
-enum F64Plane { F_X = 0, F_Y, F_VX, F_VY, F_VXO, F_VYO, F_FNX, F_FNY, F_CNX, F_CNY, NF64 };
+enum F64Plane { F_X = 0, F_Y, F_VX, F_VY, F_VXO, F_VYO, F_FNX, F_FNY, F_CNX, F_CNY, F_SCX, F_SCY, NF64 };  // F_SC*: position of the cached mine overlay
 // u32 planes, bit layout in npp_kernels.hip (pack_state / unpack_state)
 enum U32Plane { U_A = 0, U_B, U_C, U_D, U_E, NU32 };
 
@@ -50,12 +50,14 @@ struct StepOut {
     float *reward;
     uint16_t *frames;
     float *terminal_state;
+    float *spatial_context;
 };
 
 struct KernelArgs {
     double *f64;          // [NF64][n]
     uint32_t *u32;        // [NU32][n]
     uint32_t *ent_bits;   // [n_words_max][n]
+    float *sc_cache;      // [n][48] cached mine overlay of spatial_context
     const int32_t *env_level;   // [n]
     const int32_t *trunc_limit; // [n]
     const LevelHdr *hdr;  // [n_levels]

@@ -73,6 +73,8 @@ struct Stamps { unsigned long long acc[N_STAMP]; unsigned long long t0; };
 
 struct Nj {
     double x, y, vx, vy, vxo, vyo, fnx, fny, cnx, cny;
+    double scx, scy;   // where the cached mine overlay of spatial_context was computed
+    int scvalid;
     int state, airborn, airborn_old, walled, wn, jio, hor, jump, gjump, dslow;
     int jbuf, fbuf, wbuf, lbuf, cause, timpact;
     int jdur, fcount, ccount, pstate, fair, scf, frame, gold, doors, pcell;
@@ -139,6 +141,7 @@ DEV void load_state(const KernelArgs &a, int e, Nj &n) {
     n.vxo = a.f64[F_VXO * N + e]; n.vyo = a.f64[F_VYO * N + e];
     n.fnx = a.f64[F_FNX * N + e]; n.fny = a.f64[F_FNY * N + e];
     n.cnx = a.f64[F_CNX * N + e]; n.cny = a.f64[F_CNY * N + e];
+    n.scx = a.f64[F_SCX * N + e]; n.scy = a.f64[F_SCY * N + e];
     uint32_t A = a.u32[U_A * N + e], B = a.u32[U_B * N + e], C = a.u32[U_C * N + e], D = a.u32[U_D * N + e],
              E = a.u32[U_E * N + e];
     n.state = A & 15; n.airborn = (A >> 4) & 1; n.airborn_old = (A >> 5) & 1; n.walled = (A >> 6) & 1;
@@ -150,6 +153,7 @@ DEV void load_state(const KernelArgs &a, int e, Nj &n) {
     n.fair = C & 0xffff; n.scf = C >> 16;
     n.frame = D & 0xffff; n.gold = (D >> 16) & 255; n.doors = D >> 24;
     n.pcell = E & 0xffff;
+    n.scvalid = (E >> 16) & 1;
 }
 
 DEV int sat(int v, int hi) { return v > hi ? hi : v; }
@@ -161,6 +165,7 @@ DEV void store_state(const KernelArgs &a, int e, const Nj &n) {
     a.f64[F_VXO * N + e] = n.vxo; a.f64[F_VYO * N + e] = n.vyo;
     a.f64[F_FNX * N + e] = n.fnx; a.f64[F_FNY * N + e] = n.fny;
     a.f64[F_CNX * N + e] = n.cnx; a.f64[F_CNY * N + e] = n.cny;
+    a.f64[F_SCX * N + e] = n.scx; a.f64[F_SCY * N + e] = n.scy;
     uint32_t A = (uint32_t)n.state | (n.airborn << 4) | (n.airborn_old << 5) | (n.walled << 6) | ((n.wn + 1) << 7) |
                  (n.jio << 9) | ((n.hor + 1) << 10) | (n.jump << 12) | (n.gjump << 13) | (n.dslow << 14) |
                  ((n.jbuf + 1) << 15) | ((n.fbuf + 1) << 18) | ((n.wbuf + 1) << 21) | ((n.lbuf + 1) << 24) |
@@ -168,7 +173,7 @@ DEV void store_state(const KernelArgs &a, int e, const Nj &n) {
     uint32_t B = (uint32_t)sat(n.jdur, 63) | (sat(n.fcount, 255) << 6) | (sat(n.ccount, 255) << 14) | (n.pstate << 22);
     uint32_t C = (uint32_t)sat(n.fair, 0xffff) | ((uint32_t)sat(n.scf, 0xffff) << 16);
     uint32_t D = (uint32_t)sat(n.frame, 0xffff) | (sat(n.gold, 255) << 16) | ((uint32_t)sat(n.doors, 255) << 24);
-    uint32_t E = (uint32_t)n.pcell;
+    uint32_t E = (uint32_t)n.pcell | ((uint32_t)n.scvalid << 16);
     a.u32[U_A * N + e] = A; a.u32[U_B * N + e] = B; a.u32[U_C * N + e] = C; a.u32[U_D * N + e] = D;
     a.u32[U_E * N + e] = E;
 }
@@ -181,6 +186,7 @@ DEV void spawn_state(const Lv &lv, Nj &n) {
     n.gjump = 0; n.dslow = 0; n.jbuf = -1; n.fbuf = -1; n.wbuf = -1; n.lbuf = -1; n.cause = 0; n.timpact = 0;
     n.jdur = 0; n.fcount = 0; n.ccount = 0; n.pstate = 0; n.fair = 0; n.scf = 0; n.frame = 0; n.gold = 0; n.doors = 0;
     n.pcell = cell_coord(n.x, 43) * 25 + cell_coord(n.y, 24);
+    n.scx = 0; n.scy = 0; n.scvalid = 0;   // reset_mine_overlay_cache (npp_environment.py:569-571)
 }
 
 // ---- entity bits in LDS: word w of the env at w[w * stride] (stride = envs per workgroup) ----------------------------
@@ -1234,6 +1240,91 @@ DEV uint32_t action_mask_bits(const Nj &n) {
     return mask;
 }
 
+// spatial_context (112 f32): NppEnvironment._compute_spatial_context (gym_environment/npp_environment.py:2318-2360):
+//   [0, 64)   compute_local_tile_grid (gym_environment/spatial_context.py:113-176): 8 x 8 tile categories around
+//             int(x // 24), int(y // 24), read from the INNER 23 x 42 tile array with WORLD tile coordinates (the
+//             reference's off-by-one, base_environment.py:3346-3354); out of bounds = solid
+//   [64, 112) compute_mine_overlay_from_entities (:309-367 -> :370-508): 8 nearest mines (entity_dic[1] then
+//             entity_dic[21], stable sort by distance) x (dx/1056, dy/600, state code, radius code, velocity dot,
+//             distance rate), recomputed only when the ninja is >= 12 px from where it was last computed.
+// The lanes of a group split the copies; the nearest-8 selection runs redundantly on every lane.
+template <int G>
+DEV void write_spatial_context(const KernelArgs &a, const LevelHdr &H, Nj &n, EntBits eb, int env, int r, bool valid) {
+    if (!valid) return;
+    float *out = a.out.spatial_context + (size_t)env * 112;
+    float *cache = a.sc_cache + (size_t)env * 48;
+    const uint8_t *tiles = a.blob + H.off_tiles;
+    const int col = floor12(n.x) >> 1, row = floor12(n.y) >> 1;   // int(x // 24)
+    for (int k = r; k < 64; k += G) {
+        int rr = row - 4 + (k >> 3), cc = col - 4 + (k & 7);
+        int t = 1;
+        if (rr >= 0 && rr < 23 && cc >= 0 && cc < 42) {
+            t = tiles[(cc + 1) * 25 + (rr + 1)];
+            t = t > 37 ? 37 : t;
+        }
+        // categories 0 empty, 1 solid, 2 half tiles, 3 slopes, 4 curved (spatial_context.py:42-92), / 4
+        int cat = t == 0 ? 0 : (t == 1 ? 1 : (t <= 5 ? 2 : (t <= 9 ? 3 : (t <= 17 ? 4 : (t <= 33 ? 3 : 0)))));
+        out[k] = (float)cat * 0.25f;
+    }
+    bool hit = false;
+    if (n.scvalid) {
+        double dx = n.x - n.scx, dy = n.y - n.scy;
+        hit = dx * dx + dy * dy < 144.0;
+    }
+    if (hit) {
+        for (int k = r; k < 48; k += G) out[64 + k] = cache[k];
+        return;
+    }
+    double bd[8];
+    int bs[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { bd[k] = __builtin_inf(); bs[k] = -1; }
+    const uint16_t *order = reinterpret_cast<const uint16_t *>(a.blob + H.off_raster);
+    const double *ex = reinterpret_cast<const double *>(a.blob + H.off_ent_x);
+    const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);
+    const uint32_t *meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_ent_meta);
+    for (uint32_t i = 0; i < H.n_ent; i++) {
+        int slot = order[i];   // draw order = type 1 mines in map order, ..., type 21 mines in map order
+        if ((meta[slot] & 15u) != EK_MINE) continue;
+        double dx = ex[slot] - n.x, dy = ey[slot] - n.y;
+        double d = dsqrt(dx * dx + dy * dy);
+        if (!(d < bd[7])) continue;
+        bool sw = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {   // stable insertion: an equal distance stays behind earlier entries, and
+            sw = sw | (d < bd[k]);      // once placed, everything after it shifts down by one unconditionally
+            double td = bd[k]; int ts = bs[k];
+            bd[k] = sw ? d : td; bs[k] = sw ? slot : ts;
+            d = sw ? td : d; slot = sw ? ts : slot;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bs[k] >= 0) {
+            double dx = ex[bs[k]] - n.x, dy = ey[bs[k]] - n.y, dist = bd[k];
+            double vd = 0.0, dr = 0.0;
+            if (dist > 1e-6) {
+                double dirx = dx / dist, diry = dy / dist;
+                vd = (n.vx * dirx + n.vy * diry) / MAX_HOR_SPEED;
+                dr = -vd;
+            }
+            uint32_t st = ent_get(eb, bs[k]);
+            f[0] = (float)clampd(dx / 1056.0, -1.0, 1.0);
+            f[1] = (float)clampd(dy / 600.0, -1.0, 1.0);
+            f[2] = st == 1 ? 1.0f : (st == 2 ? 0.0f : -1.0f);
+            f[3] = (float)(st == 1 ? 3.5 / 5.0 : (st == 2 ? 4.5 / 5.0 : 4.0 / 5.0));
+            f[4] = (float)clampd(vd, -1.0, 1.0);
+            f[5] = (float)clampd(dr, -1.0, 1.0);
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) { cache[6 * k + j] = f[j]; out[64 + 6 * k + j] = f[j]; }
+        }
+    }
+    n.scvalid = 1; n.scx = n.x; n.scy = n.y;
+}
+
 // contiguous workgroup store of per-env rows of `width` 4-byte words staged at stage[env_in_block * width + k]
 DEV void block_store_rows(const uint32_t *stage, uint32_t *dst_block, int width, int n_valid) {
     int total = n_valid * width;
@@ -1388,6 +1479,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         block_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.entity_pos + (size_t)env0 * 6), 6, n_valid);
         __syncthreads();
     }
+    if (a.out.spatial_context) write_spatial_context<G>(a, H, n, eb, env, r, valid);
     if (a.out.action_mask && writer) {
         uint32_t m = action_mask_bits(n);
         int8_t *row = a.out.action_mask + (size_t)env * 6;

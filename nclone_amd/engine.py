@@ -54,12 +54,20 @@ class NppBatch:
             self.reward = torch.zeros((N,), dtype=torch.float32, device=self.device)
             self.frames = torch.zeros((N,), dtype=torch.int16, device=self.device)
             self.terminal_state = torch.zeros((N, 41), dtype=torch.float32, device=self.device)
+            self.spatial_context = None   # allocated by enable_spatial_context()
         self._out = nat.StepOut(
             self.game_state.data_ptr(), self.action_mask.data_ptr(), self.entity_pos.data_ptr(), self.flags.data_ptr(),
-            self.reward.data_ptr(), self.frames.data_ptr(), self.terminal_state.data_ptr(),
+            self.reward.data_ptr(), self.frames.data_ptr(), self.terminal_state.data_ptr(), None,
         )
         self._out_min = nat.StepOut(self.game_state.data_ptr(), self.action_mask.data_ptr(), self.entity_pos.data_ptr(),
-                                    self.flags.data_ptr(), self.reward.data_ptr(), self.frames.data_ptr(), None)
+                                    self.flags.data_ptr(), self.reward.data_ptr(), self.frames.data_ptr(), None, None)
+
+    def enable_spatial_context(self):
+        """Also produce the 112-float spatial_context observation (8x8 tile categories + 8 nearest mines)."""
+        if self.spatial_context is None:
+            self.spatial_context = torch.zeros((self.n, 112), dtype=torch.float32, device=self.device)
+            self._out.d_spatial_context = self.spatial_context.data_ptr()
+            self._out_min.d_spatial_context = self.spatial_context.data_ptr()
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

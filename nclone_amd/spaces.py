@@ -52,12 +52,14 @@ def action_space():
     return Discrete(6)
 
 
-def observation_space(visual=False):
+def observation_space(visual=False, spatial_context=False):
     spaces = {
         "game_state": Box(-1.0, 1.0, (41,), np.float32),
         "action_mask": Box(0, 1, (6,), np.int8),
         "entity_positions": Box(0.0, 1.0, (6,), np.float32),
     }
+    if spatial_context:
+        spaces["spatial_context"] = Box(-1.0, 1.0, (112,), np.float32)
     if visual:
         spaces["player_frame"] = Box(0, 255, (84, 84, 1), np.uint8)
     return Dict(spaces)

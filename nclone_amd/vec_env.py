@@ -38,7 +38,7 @@ class NppVecEnvironment:
     metadata = {"render_modes": []}
 
     def __init__(self, levels, num_envs, level_ids=None, frame_skip=4, device=0, enable_visual_observations=False,
-                 truncation_limit=10000, output="torch", autoreset=True):
+                 truncation_limit=10000, output="torch", autoreset=True, enable_spatial_context=False):
         assert output in ("torch", "numpy")
         self.num_envs = int(num_envs)
         self.frame_skip = int(frame_skip)
@@ -54,6 +54,8 @@ class NppVecEnvironment:
             level_ids = (np.arange(self.num_envs) // 64) % len(levels)
         self._b.assign_levels(level_ids)
         self._b.set_truncation_limit(truncation_limit)
+        if enable_spatial_context:
+            self._b.enable_spatial_context()
         self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
         self._frame = None
         if self.enable_visual_observations:
@@ -70,6 +72,8 @@ class NppVecEnvironment:
             "action_mask": self._conv(b.action_mask),
             "entity_positions": self._conv(b.entity_pos),
         }
+        if b.spatial_context is not None:
+            obs["spatial_context"] = self._conv(b.spatial_context)
         if self._frame is not None:
             b.render_player_frame(self._frame)
             obs["player_frame"] = self._conv(self._frame)

@@ -165,6 +165,10 @@ typedef struct OSim {
     EList grid[GW][GH];
     Ninja nj;
     int unsupported;          /* bitmask of entity types present but not restated */
+    /* mine-overlay cache of gym_environment/spatial_context.py:103-110,309-367 (per env = per process there) */
+    int sc_valid;
+    double sc_lx, sc_ly;
+    float sc_overlay[48];
 } OSim;
 
 static int iclamp(int n, int a, int b) { return n < a ? a : (n > b ? b : n); }
@@ -416,6 +420,7 @@ void osim_reset(OSim *S)
 {
     /* nsim.py:62-76 (reset re-creates everything) == nsim.py:78-140 (fast_reset) for these entities */
     S->frame = 0;
+    S->sc_valid = 0;   /* reset_mine_overlay_cache(): npp_environment.py:569-571 */
     ninja_init(S);
     for (int i = 0; i < S->nents; i++) {
         Entity *e = &S->ents[i];
@@ -1173,6 +1178,69 @@ int osim_action_mask(const OSim *S)
     }
     if (!mask) mask = 1;
     return mask;
+}
+
+/* spatial_context (112 f32): NppEnvironment._compute_spatial_context (gym_environment/npp_environment.py:2318-2360)
+ * = compute_local_tile_grid (gym_environment/spatial_context.py:113-176) on the INNER 23 x 42 tile array indexed with
+ * WORLD tile coordinates (the reference's off-by-one, base_environment.py:3346-3354) + compute_mine_overlay_from_entities
+ * (:309-367, :370-508) with its position cache (recomputed only after the ninja moved >= 12 px since the last compute). */
+static float sc_clipf(double v) { return (float)(v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v)); }
+
+void osim_spatial_context(OSim *S, float *out)
+{
+    static const float CAT[38] = {0, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 3,
+                                  3, 3, 3, 3, 3, 3, 3, 3, 0, 0, 0, 0};
+    const Ninja *n = &S->nj;
+    int col = (int)floor(n->xpos / 24), row = (int)floor(n->ypos / 24);   /* int(x // 24) */
+    for (int gr = 0; gr < 8; gr++)
+        for (int gc = 0; gc < 8; gc++) {
+            int r = row - 4 + gr, c = col - 4 + gc;
+            int t = 1;                                   /* out of bounds -> solid */
+            if (r >= 0 && r < 23 && c >= 0 && c < 42) {
+                t = S->tiles[c + 1][r + 1];              /* inner array element [r][c] */
+                t = t < 0 ? 0 : (t > 37 ? 37 : t);
+            }
+            out[gr * 8 + gc] = CAT[t] / 4.0f;
+        }
+    if (S->sc_valid) {
+        double dx = n->xpos - S->sc_lx, dy = n->ypos - S->sc_ly;
+        if (dx * dx + dy * dy < 144.0) { memcpy(out + 64, S->sc_overlay, sizeof(S->sc_overlay)); return; }
+    }
+    /* 8 nearest of entity_dic[1] then entity_dic[21], stable sort by distance */
+    double bd[8]; const Entity *be[8]; int nb = 0;
+    for (int i = 0; i < S->ndic; i++) {
+        const Entity *e = S->dic_order[i];
+        if (e->kind != K_MINE) continue;
+        double dx = e->x - n->xpos, dy = e->y - n->ypos;
+        double dist = POWHALF(dx * dx + dy * dy);
+        int pos = nb;
+        while (pos > 0 && dist < bd[pos - 1]) pos--;
+        if (pos >= 8) continue;
+        int last = nb < 8 ? nb : 7;
+        for (int k = last; k > pos; k--) { bd[k] = bd[k - 1]; be[k] = be[k - 1]; }
+        bd[pos] = dist; be[pos] = e;
+        if (nb < 8) nb++;
+    }
+    float *ov = S->sc_overlay;
+    memset(ov, 0, sizeof(S->sc_overlay));
+    for (int k = 0; k < nb; k++) {
+        const Entity *e = be[k];
+        double dx = e->x - n->xpos, dy = e->y - n->ypos, dist = bd[k];
+        double vd = 0.0, dr = 0.0;
+        if (dist > 1e-6) {
+            double dirx = dx / dist, diry = dy / dist;
+            vd = (n->xspeed * dirx + n->yspeed * diry) / MAX_HOR_SPEED;
+            dr = -vd;
+        }
+        ov[6 * k + 0] = sc_clipf(dx / 1056.0);
+        ov[6 * k + 1] = sc_clipf(dy / 600.0);
+        ov[6 * k + 2] = e->state == 1 ? 1.0f : (e->state == 2 ? 0.0f : -1.0f);
+        ov[6 * k + 3] = (float)(e->state == 1 ? 3.5 / 5.0 : (e->state == 2 ? 4.5 / 5.0 : 4.0 / 5.0));
+        ov[6 * k + 4] = sc_clipf(vd);
+        ov[6 * k + 5] = sc_clipf(dr);
+    }
+    S->sc_valid = 1; S->sc_lx = n->xpos; S->sc_ly = n->ypos;
+    memcpy(out + 64, ov, sizeof(S->sc_overlay));
 }
 
 /* ---- dumps used by the tests ------------------------------------------------------- */

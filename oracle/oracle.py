@@ -50,6 +50,7 @@ def _lib(variant):
     lib.osim_reset.argtypes = [P]
     lib.osim_tick.argtypes = [P, C.c_int, C.c_int]
     lib.osim_get_ninja_state.argtypes = [P, C.POINTER(C.c_double)]
+    lib.osim_spatial_context.argtypes = [P, C.POINTER(C.c_float)]
     lib.osim_action_mask.argtypes = [P]
     lib.osim_action_mask.restype = C.c_int
     lib.osim_frame.argtypes = [P]
@@ -115,6 +116,11 @@ class Oracle:
     def ninja_state(self):
         o = np.zeros(40, dtype=np.float64)
         self.lib.osim_get_ninja_state(self.h, o.ctypes.data_as(C.POINTER(C.c_double)))
+        return o
+
+    def spatial_context(self):
+        o = np.zeros(112, dtype=np.float32)
+        self.lib.osim_spatial_context(self.h, o.ctypes.data_as(C.POINTER(C.c_float)))
         return o
 
     def action_mask(self):

@@ -48,6 +48,45 @@ from nclone.sim_config import SimConfig  # noqa: E402
 from nclone.nplay_headless import NPlayHeadless  # noqa: E402
 from nclone.map_generation.generator_factory import GeneratorFactory  # noqa: E402
 
+def load_spatial_context():
+    """nclone/gym_environment/spatial_context.py is numpy-only, but importing it normally runs the package
+    __init__ of nclone.gym_environment, which needs gymnasium (not installed, an ordinary ModuleNotFoundError).
+    The module file is therefore executed directly under its own dotted name, with a bare package object registered
+    for nclone.gym_environment so that its relative imports (..constants) resolve to the real reference modules.
+    Nothing is stubbed or emulated: every line that runs is the reference's."""
+    import importlib.util
+    import types
+
+    pkg = types.ModuleType("nclone.gym_environment")
+    pkg.__path__ = [os.path.join(REF, "nclone", "gym_environment")]
+    sys.modules.setdefault("nclone.gym_environment", pkg)
+    spec = importlib.util.spec_from_file_location(
+        "nclone.gym_environment.spatial_context", os.path.join(REF, "nclone", "gym_environment", "spatial_context.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["nclone.gym_environment.spatial_context"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def inner_tiles(sim):
+    """level_data.tiles as built by base_environment.py:3346-3354 (inner 23 x 42 area)."""
+    t = np.zeros((23, 42), dtype=np.int32)
+    for (x, y), tid in sim.tile_dic.items():
+        if 0 <= x - 1 < 42 and 0 <= y - 1 < 23:
+            t[y - 1, x - 1] = int(tid)
+    return t
+
+
+def spatial_context_row(sc, hp, tiles):
+    """NppEnvironment._compute_spatial_context (npp_environment.py:2318-2360)."""
+    pos = hp.ninja_position()
+    vel = hp.ninja_velocity()
+    grid = sc.compute_local_tile_grid(pos, tiles)
+    m1, m21 = hp.get_mine_entities()
+    ov = sc.compute_mine_overlay_from_entities(pos, vel, m1, m21, 1056.0, 600.0)
+    return np.concatenate([grid, ov]).astype(np.float32)
+
+
 OUT = os.path.dirname(os.path.abspath(__file__))
 IN_SCOPE_TYPES = {1, 2, 3, 6, 21}
 ACTIONS = [(0, 0), (-1, 0), (1, 0), (0, 1), (-1, 1), (1, 1)]
@@ -302,11 +341,16 @@ def main():
             ro_levels.append((tag, lv["L%d" % k]))
     ro_names = []
     n_ro_ticks = 0
+    sc = load_spatial_context()
     for r, (tag, m) in enumerate(ro_levels):
         ro_names.append(tag)
         hp = NPlayHeadless(enable_rendering=False)
         hp.load_map_from_map_data(to_list(m))
         sim = hp.sim
+        tiles = inner_tiles(sim)
+        sc.reset_mine_overlay_cache()          # npp_environment.py:569-571 (reset)
+        sc_rows = [spatial_context_row(sc, hp, tiles)]   # observation returned by reset()
+        sc_term_rows = []
         steps = 400
         acts = np.random.default_rng(1000 + r).integers(0, 6, size=steps).astype(np.uint8)
         rows, drows, srows, grows, krows = [], [], [], [], []
@@ -326,9 +370,14 @@ def main():
             grows.append(hp.get_ninja_state())
             krows.append(mask_bits(hp.get_action_mask()))
             srows.append([executed, term, sim.frame])
+            sc_term_rows.append(spatial_context_row(sc, hp, tiles))   # observation of this step (terminal if term)
             if term:
                 hp.reset()
                 sim = hp.sim
+                sc.reset_mine_overlay_cache()
+                sc_rows.append(spatial_context_row(sc, hp, tiles))    # what a vector env returns after auto-reset
+            else:
+                sc_rows.append(sc_term_rows[-1])
         n_ro_ticks += len(rows)
         ro["m%d" % r] = m
         ro["a%d" % r] = acts
@@ -337,6 +386,8 @@ def main():
         ro["s%d" % r] = np.array(srows, dtype=np.int32).reshape(-1, 3)
         ro["g%d" % r] = np.array(grows, dtype=np.float64).astype(np.float32).reshape(-1, 40)
         ro["k%d" % r] = np.array(krows, dtype=np.uint8)
+        ro["sc%d" % r] = np.stack(sc_rows).astype(np.float32)        # [steps + 1, 112]: reset obs, then per step
+        ro["sct%d" % r] = np.stack(sc_term_rows).astype(np.float32)  # [steps, 112]: pre-reset observation
     ro["names"] = np.frombuffer("\n".join(ro_names).encode(), dtype=np.uint8)
     print("rollouts", len(ro_names), "ticks", n_ro_ticks)
 

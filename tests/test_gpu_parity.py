@@ -236,3 +236,31 @@ def test_launch_geometries_bit_identical(golden):
         else:
             for x, y in zip(ref, cur):
                 assert np.array_equal(x, y), (g, wpb)
+
+
+def test_spatial_context_matches_reference(golden, oracle_mod):
+    """spatial_context (112 f32) against rows produced by the reference's own spatial_context module, including its
+    position cache (stale between recomputes) and the reset behaviour of a vector env."""
+    r = golden.z("rollouts")
+    names = golden.names("rollouts")
+    n = len(names)
+    b = _batch(n, autoreset=True)
+    b.load_levels([r["m%d" % i] for i in range(n)])
+    b.assign_levels(np.arange(n))
+    b.enable_spatial_context()
+    b.reset()
+    b.observe()
+    sc = b.spatial_context.cpu().numpy()
+    for i in range(n):
+        assert np.abs(sc[i] - r["sc%d" % i][0]).max() <= 1.2e-7, (names[i], "reset obs", np.abs(sc[i] - r["sc%d" % i][0]).max())
+    acts = torch.from_numpy(np.stack([r["a%d" % i] for i in range(n)], axis=1)).cuda()
+    worst = 0.0
+    for s in range(acts.shape[0]):
+        b.step(acts[s])
+        sc = b.spatial_context.cpu().numpy()
+        for i in range(n):
+            ref = r["sc%d" % i][s + 1]
+            d = np.abs(sc[i] - ref).max()
+            worst = max(worst, d)
+            assert d <= 1.2e-7, (names[i], s, np.nonzero(np.abs(sc[i] - ref) > 1.2e-7)[0][:6])
+    print("spatial_context worst abs diff %.3g" % worst)

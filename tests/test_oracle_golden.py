@@ -114,3 +114,20 @@ def test_oracle_unsupported_entities_flagged(golden, oracle_mod):
         assert (uns != 0) == (not types <= {1, 2, 3, 6, 21}), (i, s, uns)
         seen += uns != 0
     assert seen == 26
+
+
+def test_oracle_spatial_context(golden, oracle_mod):
+    """spatial_context rows from the reference's spatial_context.py (loaded by file, see make_golden.py)."""
+    r = golden.z("rollouts")
+    names = golden.names("rollouts")
+    for i in range(len(names)):
+        o = oracle_mod.Oracle("pow")
+        o.load(r["m%d" % i])
+        SC, SCT = r["sc%d" % i], r["sct%d" % i]
+        assert np.array_equal(o.spatial_context(), SC[0]), names[i]
+        for s, a in enumerate(r["a%d" % i]):
+            ex, fl = o.env_step(int(a), 4)
+            assert np.array_equal(o.spatial_context(), SCT[s]), (names[i], s)
+            if fl:
+                o.reset()
+                assert np.array_equal(o.spatial_context(), SC[s + 1]), (names[i], s)
