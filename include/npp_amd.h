@@ -148,6 +148,13 @@ int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int m
                                uint32_t *unsupported_mask);
 int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out);
 
+/* Go-Explore style checkpoints (state_checkpoint.py / action_replayer.py in the reference restore a state by
+ * reset + replaying the action sequence and validating |dpos| < 0.01 px).  Here a checkpoint is a raw copy of the
+ * SoA state of ALL envs kept on the device (one slot per handle): npp_snapshot stores it, npp_restore puts it back for
+ * the envs whose mask byte is non-zero (NULL = all).  The env -> level assignment must not have changed in between. */
+int npp_snapshot(npp_handle h);
+int npp_restore(npp_handle h, const uint8_t *env_mask);
+
 /* Launch geometry: lanes_per_env wavefront lanes cooperate on one environment (power of two, 1..64; 0 = choose from
  * n_envs so that the grid fills the chip), waves_per_block wavefronts share one LDS copy of a level (1..4, 0 = auto).
  * Results are bit-identical for every geometry; only speed changes. */

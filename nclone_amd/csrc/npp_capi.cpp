@@ -22,6 +22,13 @@ struct npp_handle_s {
     uint32_t *d_u32 = nullptr;
     uint32_t *d_ent = nullptr;
     float *d_sc_cache = nullptr;
+    // snapshot slot (npp_snapshot / npp_restore)
+    double *s_f64 = nullptr;
+    uint32_t *s_u32 = nullptr;
+    uint32_t *s_ent = nullptr;
+    float *s_sc = nullptr;
+    int s_words = 0;
+    unsigned long long assign_gen = 0, s_gen = ~0ull;
     int32_t *d_env_level = nullptr;
     int32_t *d_trunc = nullptr;
     uint8_t *d_mask = nullptr;
@@ -179,6 +186,7 @@ int npp_destroy(npp_handle h) {
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache);
+    hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc);
     delete h;
     return NPP_OK;
 }
@@ -192,6 +200,45 @@ int npp_set_stream(npp_handle h, void *hip_stream) {
 int npp_sync(npp_handle h) {
     if (!h) return NPP_ERR_INVALID;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NPP_OK;
+}
+
+int npp_snapshot(npp_handle h) {
+    if (!h) return NPP_ERR_INVALID;
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_snapshot: no levels loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t N = (size_t)h->n;
+    if (!h->s_f64) {
+        HIP_TRY(h, hipMalloc((void **)&h->s_f64, sizeof(double) * NF64 * N));
+        HIP_TRY(h, hipMalloc((void **)&h->s_u32, sizeof(uint32_t) * NU32 * N));
+        HIP_TRY(h, hipMalloc((void **)&h->s_sc, sizeof(float) * 48 * N));
+    }
+    if (h->s_words != h->n_words_max) {
+        hipFree(h->s_ent);
+        h->s_ent = nullptr;
+        HIP_TRY(h, hipMalloc((void **)&h->s_ent, sizeof(uint32_t) * (size_t)h->n_words_max * N));
+        h->s_words = h->n_words_max;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->s_f64, h->d_f64, sizeof(double) * NF64 * N, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->s_u32, h->d_u32, sizeof(uint32_t) * NU32 * N, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->s_ent, h->d_ent, sizeof(uint32_t) * (size_t)h->n_words_max * N, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->s_sc, h->d_sc_cache, sizeof(float) * 48 * N, hipMemcpyDeviceToDevice, h->stream));
+    h->s_gen = h->assign_gen;
+    return NPP_OK;
+}
+
+int npp_restore(npp_handle h, const uint8_t *env_mask) {
+    if (!h) return NPP_ERR_INVALID;
+    if (!h->s_f64 || h->s_gen != h->assign_gen)
+        return fail(h, NPP_ERR_STATE, "npp_restore: no snapshot for the current level assignment");
+    HIP_TRY(h, hipSetDevice(h->device));
+    KernelArgs a = base_args(h);
+    if (env_mask) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        a.reset_mask = h->d_mask;
+    }
+    HIP_TRY(h, launch_restore(a, h->s_f64, h->s_u32, h->s_ent, h->s_sc, h->stream));
+    if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NPP_OK;
 }
 
@@ -290,6 +337,7 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     HIP_TRY(h, hipMemset(h->d_ent, 0, sizeof(uint32_t) * (size_t)words_max * h->n));
     h->levels.swap(lv);
     h->hdrs.swap(hdrs);
+    h->assign_gen++;
     h->n_words_max = words_max;
     h->hot_max = hot_max;
     std::fill(h->env_level.begin(), h->env_level.end(), 0);
@@ -313,6 +361,7 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
         h->env_level[e] = level_ids[i];
         mask[e] = 1;
     }
+    h->assign_gen++;
     plan_geometry(h);
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

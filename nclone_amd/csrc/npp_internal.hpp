@@ -87,6 +87,9 @@ inline size_t lds_bytes(uint32_t hot_cap, int n_words_max, int envs_per_block) {
 
 hipError_t launch_step(const KernelArgs &a, hipStream_t s);
 hipError_t launch_reset(const KernelArgs &a, hipStream_t s);
+// per-env copy of every state plane from `src` into the live state (a.reset_mask selects envs; NULL = all)
+hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint32_t *src_u32, const uint32_t *src_ent,
+                          const float *src_sc, hipStream_t s);
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
 
 }  // namespace npp

@@ -1524,6 +1524,19 @@ __global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
     for (uint32_t w = 0; w < H.n_words; w++) a.ent_bits[(size_t)w * a.n + env] = init[w];
 }
 
+// npp_restore: copy the snapshot planes of the masked envs back into the live state
+__global__ __launch_bounds__(256) void npp_restore_kernel(KernelArgs a, const double *sf, const uint32_t *su, const uint32_t *se,
+                                                          const float *sc) {
+    const int env = blockIdx.x * 256 + threadIdx.x;
+    if (env >= a.n) return;
+    if (a.reset_mask && a.reset_mask[env] == 0) return;
+    const size_t N = (size_t)a.n;
+    for (int k = 0; k < NF64; k++) a.f64[k * N + env] = sf[k * N + env];
+    for (int k = 0; k < NU32; k++) a.u32[k * N + env] = su[k * N + env];
+    for (int k = 0; k < a.n_words_max; k++) a.ent_bits[k * N + env] = se[k * N + env];
+    for (int k = 0; k < 48; k++) a.sc_cache[(size_t)env * 48 + k] = sc[(size_t)env * 48 + k];
+}
+
 template <int G>
 hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
     const int wpb = a.waves_per_block;
@@ -1548,6 +1561,12 @@ hipError_t launch_step(const KernelArgs &a, hipStream_t s) {
         case 64: return launch_step_g<64>(a, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint32_t *src_u32, const uint32_t *src_ent,
+                          const float *src_sc, hipStream_t s) {
+    hipLaunchKernelGGL(npp_restore_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a, src_f64, src_u32, src_ent, src_sc);
+    return hipGetLastError();
 }
 
 hipError_t launch_reset(const KernelArgs &a, hipStream_t s) {

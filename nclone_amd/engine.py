@@ -142,6 +142,19 @@ class NppBatch:
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 84 * 84 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_render_player_frame(self.h, C.c_void_p(out.data_ptr())))
 
+    def snapshot(self):
+        """Checkpoint the state of every env on the device (one slot)."""
+        nat.check(self.h, self.lib.npp_snapshot(self.h))
+
+    def restore(self, mask=None):
+        """Put the checkpointed state back (for the masked envs; None = all)."""
+        if mask is None:
+            nat.check(self.h, self.lib.npp_restore(self.h, None))
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert len(m) == self.n
+            nat.check(self.h, self.lib.npp_restore(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
     def sync(self):
         nat.check(self.h, self.lib.npp_sync(self.h))
 

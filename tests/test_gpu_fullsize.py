@@ -113,3 +113,50 @@ def test_truncation_and_terminal_envs_stay_put():
             else:
                 done_at[e] = s
     assert len(done_at) > 0
+
+
+def test_checkpoint_snapshot_restore_and_action_replay():
+    """a checkpoint is a raw SoA copy (npp_snapshot / npp_restore); it must equal what the
+    reference's ActionReplayer reaches by reset + replaying the action sequence (action_replayer.py, validated there
+    with |dpos| < 0.01 px -- here bit-for-bit), and restoring must make the future identical."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import mine_levels
+
+    levels, _ = mine_levels()
+    n = 1024
+    b = NppBatch(n, autoreset=False)
+    b.load_levels(levels[:8])
+    b.assign_levels((np.arange(n) // 64) % 8)
+    b.enable_spatial_context()
+    rng = np.random.default_rng(21)
+    acts = torch.from_numpy(rng.integers(0, 6, size=(50, n)).astype(np.uint8)).cuda()
+    for s in range(25):
+        b.step(acts[s])
+    b.snapshot()
+    f0, i0 = b.dump_state()
+    for s in range(25, 50):
+        b.step(acts[s])
+    f1, i1 = b.dump_state()
+    sc1 = b.spatial_context.cpu().numpy().copy()
+    # restore everything -> same future
+    b.restore()
+    fr, ir = b.dump_state()
+    assert np.array_equal(fr, f0) and np.array_equal(ir, i0)
+    for s in range(25, 50):
+        b.step(acts[s])
+    f2, i2 = b.dump_state()
+    assert np.array_equal(f2, f1) and np.array_equal(i2, i1)
+    assert np.array_equal(b.spatial_context.cpu().numpy(), sc1)
+    # partial restore
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[::2] = 1
+    b.restore(mask)
+    fp, ip = b.dump_state()
+    assert np.array_equal(fp[::2], f0[::2]) and np.array_equal(fp[1::2], f1[1::2])
+    # the reference's way: reset + replay the action sequence reaches the checkpoint exactly
+    b.reset()
+    for s in range(25):
+        b.step(acts[s])
+    fa, ia = b.dump_state()
+    assert np.array_equal(fa, f0) and np.array_equal(ia, i0)
+    assert np.abs(fa[:, :2] - f0[:, :2]).max() < 0.01   # POSITION_VALIDATION_THRESHOLD (state_checkpoint.py)
