@@ -7,7 +7,13 @@
  * Parity status: PINNED.  In the build container this restatement is checked
  * bit-for-bit (fp64 positions/velocities, every discrete field) against fixtures
  * produced by running the reference itself (tests/golden/make_golden.py): all 104
- * in-scope bc_replays (25 575 ticks) plus 31 random-action rollouts (49 396 ticks).
+ * in-scope bc_replays (25 575 ticks) plus 31 random-action rollouts (49 396 ticks), and
+ * -- with the entity zoo of SURVEY.md 8(f) row 2 (regular/trap doors, launch pads, one-way
+ * platforms, zap and mini drones, bounce blocks, thwumps, boost pads, death balls, shove
+ * thwumps) -- the remaining 26 bc_replays (5 886 ticks, per-tick entity checksums) and
+ * 9 zoo rollouts (10 776 ticks) from tests/golden/make_golden_zoo.py: 130 of 130 replays.
+ * Regular doors (type 5) occur in none of the reference's maps: restated from
+ * entity_door_regular.py, parity unpinned for that one kind.
  *
  * Where the reference writes `x**2` CPython calls libm pow(|x|, 2.0), which is NOT
  * always equal to x*x on glibc.  The default build uses
@@ -22,6 +28,7 @@
  */
 #define _GNU_SOURCE
 #include <math.h>
+#include <alloca.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -70,6 +77,17 @@ static const char *ORTHO[34] = {
     "-.....--....", ".-........++", ".....+....++", "....+.--....",
     "--..+.--....", "--...+....++", ".-..++....++", "-...++--....",
 };
+/* GEDGE[t]: tile_definitions.py TILE_GRID_EDGE_MAP, same 6 + 6 half-edge layout as ORTHO, '1' = edge present */
+static const char *GEDGE[34] = {
+    "000000000000", "110011110011", "111100100010", "010001001111", "001111010001", "100010111100",
+    "110110110110", "111001100111", "011011011011", "100111111001",
+    "110011110011", "110011110011", "110011110011", "110011110011",
+    "110110110110", "111001100111", "011011011011", "100111111001",
+    "111100100010", "111100100010", "001111010001", "001111010001",
+    "110011110011", "110011110011", "110011110011", "110011110011",
+    "100010111100", "010001001111", "010001001111", "100010111100",
+    "110011110011", "110011110011", "110011110011", "110011110011",
+};
 /* DIAG[t] = x1,y1,x2,y2 for t in 6..9 and 18..33 (tile_definitions.py:189-210) */
 static const signed char DIAG[34][4] = {
     {0,0,0,0},{0,0,0,0},{0,0,0,0},{0,0,0,0},{0,0,0,0},{0,0,0,0},
@@ -105,7 +123,9 @@ typedef struct {
     double b[4];
 } IndexCell;                  /* utils/spatial_segment_index.py:69-110 */
 
-enum { K_MINE = 1, K_GOLD = 2, K_EXIT = 3, K_SWITCH = 4, K_LOCKED = 6 };
+enum { K_MINE = 1, K_GOLD = 2, K_EXIT = 3, K_SWITCH = 4, K_DOOR_REG = 5, K_LOCKED = 6, K_DOOR_TRAP = 8,
+       K_LAUNCH = 10, K_ONEWAY = 11, K_DRONE = 14, K_BOUNCE = 17, K_THWUMP = 20, K_BOOST = 24, K_BALL = 25,
+       K_SHOVE = 28 };   /* K_DRONE covers zap drones (14) and mini drones (26) */
 
 typedef struct Entity {
     int dic_key;              /* entity_dic key the object lives under */
@@ -118,8 +138,23 @@ typedef struct Entity {
     double radius;
     int switch_hit;           /* exit door */
     struct Entity *parent;    /* exit switch -> door */
-    int closed;               /* locked door */
-    int thinkable, logical;
+    int closed;               /* doors */
+    int thinkable, logical, movable, physical;
+    /* ---- entity zoo ---- */
+    double x0, y0;            /* position at creation */
+    int cx0, cy0;
+    int orientation, mode;
+    double nx, ny;            /* launch pad / one-way normal (physics.py:317-332) */
+    double xspeed, yspeed;    /* bounce block, death ball */
+    double xorigin, yorigin;  /* bounce block, thwump, shove thwump */
+    double speed, xtarget, ytarget, drone_radius, grid_width;   /* drones */
+    int dir;
+    int is_horizontal, direction;   /* thwump */
+    double xdir, ydir;        /* shove thwump */
+    int activated;
+    int touching;             /* boost pad */
+    int is_vertical, edge[2][2], open_timer;   /* doors: grid edges they own (entity_door_base.py:69-89) */
+    int index;                /* Entity.index (entities.py: per-type creation counter) */
 } Entity;
 
 typedef struct {
@@ -165,6 +200,14 @@ typedef struct OSim {
     EList grid[GW][GH];
     Ninja nj;
     int unsupported;          /* bitmask of entity types present but not restated */
+    /* grid edges used by drones / thwumps (nsim.py:208-215, tile_segment_factory.py:283-302, doors) */
+    int hor_base[89][51], ver_base[89][51];
+    int hor_edge[89][51], ver_edge[89][51];
+    int has_zoo;              /* any movable / physically collidable / extra thinkable entity */
+    int creations;            /* number of times the entities were (re)created since load: sim.entity_counts persists
+                                 across Simulator.reset(), so Entity.index keeps growing (entities.py:129-133) */
+    Entity *cached[256];      /* ninja._cached_entities (ninja.py:220-222) */
+    int ncached;
     /* mine-overlay cache of gym_environment/spatial_context.py:103-110,309-367 (per env = per process there) */
     int sc_valid;
     double sc_lx, sc_ly;
@@ -223,6 +266,24 @@ static void build_geometry(OSim *S)
             double v = S->map[184 + x + y * 42];
             int t = (v == floor(v) && v >= 0 && v < 256) ? (int)v : 255;
             S->tiles[x + 1][y + 1] = t;
+        }
+    /* grid edges: nsim.py:208-215 (outer frame preset to 1) then tile_segment_factory.py:283-302 (mod-2 toggles) */
+    for (int xc = 0; xc < 89; xc++)
+        for (int yc = 0; yc < 51; yc++) {
+            S->hor_base[xc][yc] = (yc == 0 || yc == 50) ? 1 : 0;
+            S->ver_base[xc][yc] = (xc == 0 || xc == 88) ? 1 : 0;
+        }
+    for (int x = 0; x < GW; x++)
+        for (int y = 0; y < GH; y++) {
+            int t = S->tiles[x][y];
+            if (t == 0 || t >= 34) continue;
+            const char *g = GEDGE[t];
+            for (int j = 0; j < 3; j++)
+                for (int i = 0; i < 2; i++)
+                    S->hor_base[2 * x + i][2 * y + j] = (S->hor_base[2 * x + i][2 * y + j] + (g[2 * j + i] - '0')) % 2;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 2; j++)
+                    S->ver_base[2 * x + i][2 * y + j] = (S->ver_base[2 * x + i][2 * y + j] + (g[2 * i + j + 6] - '0')) % 2;
         }
     /* tile_segment_factory.py:170-215; the iteration order over tiles only matters for the
      * (at most one) diagonal/arc of a cell, which is always first in its cell's list. */
@@ -326,6 +387,41 @@ static void mine_set_state(Entity *e, int st)
     e->radius = st == 0 ? 4.0 : (st == 1 ? 3.5 : 4.5);
 }
 
+/* physics.py:317-332 */
+static void orientation_vector(int o, double *vx, double *vy)
+{
+    double diag = sqrt(2.0) / 2;
+    static const int sx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, sy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    o &= 7;
+    if (o & 1) { *vx = sx[o] * diag; *vy = sy[o] * diag; }
+    else { *vx = sx[o]; *vy = sy[o]; }
+}
+
+/* entity_door_base.py:52-97: the door's own position decides the grid edges it blocks, then the entity moves to
+ * its switch.  The door segment itself never reaches the ninja's queries. */
+static void door_init(Entity *e, int orientation, double sw_xc, double sw_yc)
+{
+    double vx, vy;
+    orientation_vector(orientation, &vx, &vy);
+    e->orientation = orientation;
+    e->is_vertical = (orientation == 0 || orientation == 4);
+    int dcx = iclamp((int)floor((e->x - 12 * vx) / 24), 0, 43);
+    int dcy = iclamp((int)floor((e->y - 12 * vy) / 24), 0, 24);
+    int hx = 2 * (dcx + 1), hy = 2 * (dcy + 1);
+    if (e->is_vertical) {
+        e->edge[0][0] = hx; e->edge[0][1] = hy - 2;
+        e->edge[1][0] = hx; e->edge[1][1] = hy - 1;
+    } else {
+        e->edge[0][0] = hx - 2; e->edge[0][1] = hy;
+        e->edge[1][0] = hx - 1; e->edge[1][1] = hy;
+    }
+    e->x = 6 * sw_xc;
+    e->y = 6 * sw_yc;
+    e->cx = iclamp((int)floor(e->x / 24), 0, 43);
+    e->cy = iclamp((int)floor(e->y / 24), 0, 24);
+    e->logical = 1;
+}
+
 static void load_entities(OSim *S)
 {
     int n = S->nmap;
@@ -334,6 +430,9 @@ static void load_entities(OSim *S)
     S->ents = calloc(cap, sizeof(Entity));
     S->nents = 0;
     S->unsupported = 0;
+    S->has_zoo = 0;
+    int counts[40];
+    memset(counts, 0, sizeof(counts));
     int index = 1230;
     double exit_door_count = n > 1156 ? m[1156] : 0;
     while (index < n) {
@@ -341,6 +440,7 @@ static void load_entities(OSim *S)
         double tv = m[index];
         int type = (tv == floor(tv) && tv >= 0 && tv < 64) ? (int)tv : -1;
         double xc = m[index + 1], yc = m[index + 2];
+        int orientation = (int)m[index + 3], mode = (int)m[index + 4];
         Entity *e = NULL;
         if (type == 1 || type == 21) {
             e = &S->ents[S->nents++];
@@ -358,21 +458,72 @@ static void load_entities(OSim *S)
             Entity *door = &S->ents[S->nents++];
             ent_base(door, 3, xc, yc);
             door->kind = K_EXIT; door->dic_key = 3; door->logical = 1; door->radius = 12;
+            door->x0 = door->x; door->y0 = door->y; door->cx0 = door->cx; door->cy0 = door->cy;
             int ci = index + 5 * (int)exit_door_count;
             double sx = (ci + 2 < n) ? m[ci + 1] : 0, sy = (ci + 2 < n) ? m[ci + 2] : 0;
             e = &S->ents[S->nents++];
             ent_base(e, 4, sx, sy);
             e->kind = K_SWITCH; e->dic_key = 3; e->logical = 1; e->radius = 6; e->parent = door;
-        } else if (type == 6) {
-            /* entity_door_base.py:52-97, entity_door_locked.py:46-52: the entity sits at its switch.
-             * Its door segment never reaches the ninja's queries. */
+        } else if (type == 5) {
+            /* entity_factory.py:198-201, entity_door_regular.py:41-44: the switch is the door itself */
+            e = &S->ents[S->nents++];
+            ent_base(e, 5, xc, yc);
+            e->kind = K_DOOR_REG; e->dic_key = 5; e->radius = 10; e->thinkable = 1;
+            door_init(e, orientation, xc, yc);
+        } else if (type == 6 || type == 8) {
+            /* entity_factory.py:202-216, entity_door_locked.py:46-52, entity_door_trap.py:51-58 */
             double sx = (index + 7 < n) ? m[index + 6] : 0, sy = (index + 7 < n) ? m[index + 7] : 0;
             e = &S->ents[S->nents++];
-            ent_base(e, 6, sx, sy);
-            e->kind = K_LOCKED; e->dic_key = 6; e->logical = 1; e->radius = 5; e->closed = 1;
-        } else if (type == 5 || type == 8 || type == 10 || type == 11 || type == 14 || type == 17 ||
-                   type == 20 || type == 24 || type == 25 || type == 26 || type == 28) {
-            S->unsupported |= 1 << (type < 31 ? type : 31);
+            ent_base(e, type, xc, yc);
+            e->kind = type == 6 ? K_LOCKED : K_DOOR_TRAP; e->dic_key = type; e->radius = 5;
+            door_init(e, orientation, sx, sy);
+        } else if (type == 10) {
+            e = &S->ents[S->nents++];
+            ent_base(e, 10, xc, yc);
+            e->kind = K_LAUNCH; e->dic_key = 10; e->logical = 1; e->radius = 6; e->orientation = orientation;
+            orientation_vector(orientation, &e->nx, &e->ny);
+        } else if (type == 11) {
+            e = &S->ents[S->nents++];
+            ent_base(e, 11, xc, yc);
+            e->kind = K_ONEWAY; e->dic_key = 11; e->logical = 1; e->physical = 1; e->orientation = orientation;
+            orientation_vector(orientation, &e->nx, &e->ny);
+        } else if (type == 14 || type == 26) {
+            /* entity_drone_zap.py:53-55 (speed 8/7, radius 7.5, grid 24), entity_mini_drone.py:56-58 (1.3, 4, 12) */
+            e = &S->ents[S->nents++];
+            ent_base(e, type, xc, yc);
+            e->kind = K_DRONE; e->dic_key = type; e->logical = 1; e->movable = 1;
+            e->speed = type == 14 ? 8.0 / 7 : 1.3;
+            e->drone_radius = type == 14 ? 7.5 : 4.0;
+            e->grid_width = type == 14 ? 24 : 12;
+            e->orientation = orientation; e->mode = mode & 3;
+        } else if (type == 17) {
+            e = &S->ents[S->nents++];
+            ent_base(e, 17, xc, yc);
+            e->kind = K_BOUNCE; e->dic_key = 17; e->logical = 1; e->physical = 1; e->movable = 1;
+        } else if (type == 20) {
+            e = &S->ents[S->nents++];
+            ent_base(e, 20, xc, yc);
+            e->kind = K_THWUMP; e->dic_key = 20; e->logical = 1; e->physical = 1; e->movable = 1; e->thinkable = 1;
+            e->orientation = orientation;
+            e->is_horizontal = (orientation == 0 || orientation == 4);
+            e->direction = (orientation == 0 || orientation == 2) ? 1 : -1;
+        } else if (type == 24) {
+            e = &S->ents[S->nents++];
+            ent_base(e, 24, xc, yc);
+            e->kind = K_BOOST; e->dic_key = 24; e->movable = 1; e->radius = 6;
+        } else if (type == 25) {
+            e = &S->ents[S->nents++];
+            ent_base(e, 25, xc, yc);
+            e->kind = K_BALL; e->dic_key = 25; e->thinkable = 1; e->logical = 1;
+        } else if (type == 28) {
+            e = &S->ents[S->nents++];
+            ent_base(e, 28, xc, yc);
+            e->kind = K_SHOVE; e->dic_key = 28; e->thinkable = 1; e->logical = 1; e->physical = 1;
+        }
+        if (e) {
+            e->x0 = e->x; e->y0 = e->y; e->cx0 = e->cx; e->cy0 = e->cy;
+            e->index = counts[e->type < 40 ? e->type : 39]++;
+            if (e->kind == K_DOOR_REG || e->kind >= K_DOOR_TRAP) S->has_zoo = 1;
         }
         if (type == 6 || type == 8) {
             if (index + 9 < n) {
@@ -389,6 +540,14 @@ static void load_entities(OSim *S)
             if (S->ents[i].dic_key == key) S->dic_order[S->ndic++] = &S->ents[i];
 }
 
+static void door_edges_add(OSim *S, const Entity *e, int d)
+{   /* entity_door_base.py:78-89,104-108: plain integer counters (they can go negative, and negative is truthy) */
+    for (int k = 0; k < 2; k++) {
+        if (e->is_vertical) S->ver_edge[e->edge[k][0]][e->edge[k][1]] += d;
+        else S->hor_edge[e->edge[k][0]][e->edge[k][1]] += d;
+    }
+}
+
 static void grid_rebuild(OSim *S)
 {
     for (int x = 0; x < GW; x++)
@@ -399,6 +558,22 @@ static void grid_rebuild(OSim *S)
         if (e->kind == K_EXIT) continue;
         elist_push(&S->grid[e->cx][e->cy], e);
     }
+}
+
+/* entities.py Entity.grid_move: leave the old cell's list, join the END of the new cell's list */
+static void grid_move(OSim *S, Entity *e)
+{
+    int ncx = iclamp((int)floor(e->x / 24), 0, 43), ncy = iclamp((int)floor(e->y / 24), 0, 24);
+    if (ncx == e->cx && ncy == e->cy) return;
+    EList *l = &S->grid[e->cx][e->cy];
+    for (int k = 0; k < l->n; k++)
+        if (l->e[k] == e) {
+            memmove(&l->e[k], &l->e[k + 1], sizeof(Entity *) * (l->n - k - 1));
+            l->n--;
+            break;
+        }
+    e->cx = ncx; e->cy = ncy;
+    elist_push(&S->grid[ncx][ncy], e);
 }
 
 static void ninja_init(OSim *S)
@@ -418,16 +593,36 @@ static void ninja_init(OSim *S)
 
 void osim_reset(OSim *S)
 {
-    /* nsim.py:62-76 (reset re-creates everything) == nsim.py:78-140 (fast_reset) for these entities */
+    /* nsim.py:62-76: Simulator.reset() re-creates every entity from map_data (the semantics restated here;
+     * fast_reset, nsim.py:78-140, is equivalent for the entity kinds that implement reset_state()) */
     S->frame = 0;
     S->sc_valid = 0;   /* reset_mine_overlay_cache(): npp_environment.py:569-571 */
+    S->creations += 1;
+    S->ncached = 0;
     ninja_init(S);
+    memcpy(S->hor_edge, S->hor_base, sizeof(S->hor_edge));
+    memcpy(S->ver_edge, S->ver_base, sizeof(S->ver_edge));
     for (int i = 0; i < S->nents; i++) {
         Entity *e = &S->ents[i];
         e->active = 1;
-        if (e->kind == K_MINE) mine_set_state(e, e->init_state);
-        if (e->kind == K_EXIT) e->switch_hit = 0;
-        if (e->kind == K_LOCKED) e->closed = 1;
+        e->x = e->x0; e->y = e->y0; e->cx = e->cx0; e->cy = e->cy0;
+        switch (e->kind) {
+        case K_MINE: mine_set_state(e, e->init_state); break;
+        case K_EXIT: e->switch_hit = 0; break;
+        case K_LOCKED: e->closed = 1; door_edges_add(S, e, 1); break;
+        case K_DOOR_REG: e->closed = 1; e->open_timer = 0; door_edges_add(S, e, 1); break;
+        case K_DOOR_TRAP: e->closed = 0; door_edges_add(S, e, 1); door_edges_add(S, e, -1); break;
+        case K_DRONE:     /* entity_drone_base.py:74-84 */
+            e->dir = e->orientation / 2;
+            e->xtarget = e->x; e->ytarget = e->y;
+            break;
+        case K_BOUNCE: e->xspeed = e->yspeed = 0; e->xorigin = e->x; e->yorigin = e->y; break;
+        case K_THWUMP: e->xorigin = e->x; e->yorigin = e->y; e->state = 0; break;
+        case K_BOOST: e->touching = 0; break;
+        case K_BALL: e->xspeed = e->yspeed = 0; break;
+        case K_SHOVE: e->xorigin = e->x; e->yorigin = e->y; e->xdir = e->ydir = 0; e->state = 0; e->activated = 0; break;
+        default: break;
+        }
     }
     grid_rebuild(S);
 }
@@ -465,6 +660,7 @@ int osim_load(OSim *S, const double *map, int n)
     S->nmap = n;
     build_geometry(S);
     load_entities(S);
+    S->creations = 0;   /* a load restated here is a fresh Simulator */
     osim_reset(S);
     return S->unsupported;
 }
@@ -691,6 +887,429 @@ static void ninja_win(Ninja *n)
     }
 }
 
+/* physics.py:16-18, 210-235 */
+static int half_x(int x) { return iclamp(x, 0, 87); }
+static int half_y(int y) { return iclamp(y, 0, 49); }
+
+static int is_empty_row(const OSim *S, int x1, int x2, int y, int dir)
+{
+    if (dir != 1 && dir != -1) return 0;   /* the reference returns None there, which its callers read as "blocked" */
+    int yy = half_y(dir == 1 ? y + 1 : y);
+    for (int x = x1; x <= x2; x++)
+        if (S->hor_edge[half_x(x)][yy]) return 0;
+    return 1;
+}
+
+static int is_empty_column(const OSim *S, int x, int y1, int y2, int dir)
+{
+    if (dir != 1 && dir != -1) return 0;
+    int xx = half_x(dir == 1 ? x + 1 : x);
+    for (int y = y1; y <= y2; y++)
+        if (S->ver_edge[xx][half_y(y)]) return 0;
+    return 1;
+}
+
+/* physics.py:183-201; returns 0 when there is no penetration */
+static int penetration_square_vs_point(double sx, double sy, double px, double py, double semi_side,
+                                       double *nx, double *ny, double *len, double *len2)
+{
+    double dx = px - sx, dy = py - sy;
+    double penx = semi_side - fabs(dx), peny = semi_side - fabs(dy);
+    if (penx > 0 && peny > 0) {
+        if (peny <= penx) { *nx = 0; *ny = dy < 0 ? -1 : 1; *len = peny; *len2 = penx; }
+        else { *nx = dx < 0 ? -1 : 1; *ny = 0; *len = penx; *len2 = peny; }
+        return 1;
+    }
+    return 0;
+}
+
+/* physics.py:457-471 */
+static int overlap_circle_vs_segment(double xpos, double ypos, double radius, double px1, double py1, double px2, double py2)
+{
+    double px = px2 - px1, py = py2 - py1;
+    double dx = xpos - px1, dy = ypos - py1;
+    double seg_lensq = SQ(px) + SQ(py);
+    double u = (dx * px + dy * py) / seg_lensq;
+    u = pymax(u, 0);
+    u = pymin(u, 1);
+    double a = px1 + u * px, b = py1 + u * py;
+    return SQ(xpos - a) + SQ(ypos - b) < SQ(radius);
+}
+
+static const int DIR_VX[4] = {1, 0, -1, 0}, DIR_VY[4] = {0, 1, 0, -1};       /* entity_drone_base.py:68 */
+static const int DIR_LIST[4][4] = {{1, 0, 3, 2}, {3, 0, 1, 2}, {0, 1, 3, 2}, {0, 3, 1, 2}};   /* :72 */
+
+/* entity_drone_base.py:138-164 */
+static int drone_test_direction(OSim *S, Entity *e, int dir)
+{
+    int xdir = DIR_VX[dir], ydir = DIR_VY[dir];
+    double xtarget = e->x + e->grid_width * xdir;
+    double ytarget = e->y + e->grid_width * ydir;
+    double R = e->drone_radius;
+    if (!ydir) {
+        int cell_x = (int)floor((e->x + xdir * R) / 12);
+        int cell_xtarget = (int)floor((xtarget + xdir * R) / 12);
+        int cell_y1 = (int)floor((e->y - R) / 12);
+        int cell_y2 = (int)floor((e->y + R) / 12);
+        while (cell_x != cell_xtarget) {
+            if (!is_empty_column(S, cell_x, cell_y1, cell_y2, xdir)) return 0;
+            cell_x += xdir;
+        }
+    } else {
+        int cell_y = (int)floor((e->y + ydir * R) / 12);
+        int cell_ytarget = (int)floor((ytarget + ydir * R) / 12);
+        int cell_x1 = (int)floor((e->x - R) / 12);
+        int cell_x2 = (int)floor((e->x + R) / 12);
+        while (cell_y != cell_ytarget) {
+            if (!is_empty_row(S, cell_x1, cell_x2, cell_y, ydir)) return 0;
+            cell_y += ydir;
+        }
+    }
+    e->xtarget = xtarget;
+    e->ytarget = ytarget;
+    return 1;
+}
+
+/* entity_drone_base.py:93-136 */
+static void drone_move(OSim *S, Entity *e)
+{
+    double xspeed = e->speed * DIR_VX[e->dir], yspeed = e->speed * DIR_VY[e->dir];
+    double dx = e->xtarget - e->x, dy = e->ytarget - e->y;
+    double dist = sqrt(SQ(dx) + SQ(dy));
+    if (dist < 0.000001 || (dx * (e->xtarget - (e->x + xspeed)) + dy * (e->ytarget - (e->y + yspeed))) < 0) {
+        e->x = e->xtarget;
+        e->y = e->ytarget;
+        int can_move = 0;
+        for (int i = 0; i < 4; i++) {
+            int new_dir = (e->dir + DIR_LIST[e->mode][i]) % 4;
+            if (drone_test_direction(S, e, new_dir)) { e->dir = new_dir; can_move = 1; break; }
+        }
+        if (can_move) {
+            double disp = e->speed - dist;
+            e->x += disp * DIR_VX[e->dir];
+            e->y += disp * DIR_VY[e->dir];
+        }
+    } else {
+        e->x += xspeed;
+        e->y += yspeed;
+        grid_move(S, e);
+    }
+}
+
+/* entity_bounce_block.py:107-125 (the data-tracking tail does not feed back into the physics) */
+static void bounce_move(OSim *S, Entity *e)
+{
+    e->xspeed *= 0.98;
+    e->yspeed *= 0.98;
+    e->x += e->xspeed;
+    e->y += e->yspeed;
+    double xforce = 0.02222222222222222 * (e->xorigin - e->x);
+    double yforce = 0.02222222222222222 * (e->yorigin - e->y);
+    e->x += xforce;
+    e->y += yforce;
+    e->xspeed += xforce;
+    e->yspeed += yforce;
+    grid_move(S, e);
+}
+
+/* entity_thwump.py:109-156 */
+static void thwump_move(OSim *S, Entity *e)
+{
+    if (!e->state) return;
+    double speed = e->state == 1 ? 20.0 / 7 : 8.0 / 7;
+    int speed_dir = e->direction * e->state;
+    if (!e->is_horizontal) {
+        double ypos_new = e->y + speed * speed_dir;
+        if (e->state == -1 && (ypos_new - e->yorigin) * (e->y - e->yorigin) < 0) {
+            e->y = e->yorigin;
+            e->state = 0;
+            return;
+        }
+        int cell_y = (int)floor((e->y + speed_dir * 11) / 12);
+        int cell_y_new = (int)floor((ypos_new + speed_dir * 11) / 12);
+        if (cell_y != cell_y_new) {
+            int cell_x1 = (int)floor((e->x - 11) / 12), cell_x2 = (int)floor((e->x + 11) / 12);
+            if (!is_empty_row(S, cell_x1, cell_x2, cell_y, speed_dir)) { e->state = -1; return; }
+        }
+        e->y = ypos_new;
+    } else {
+        double xpos_new = e->x + speed * speed_dir;
+        if (e->state == -1 && (xpos_new - e->xorigin) * (e->x - e->xorigin) < 0) {
+            e->x = e->xorigin;
+            e->state = 0;
+            return;
+        }
+        int cell_x = (int)floor((e->x + speed_dir * 11) / 12);
+        int cell_x_new = (int)floor((xpos_new + speed_dir * 11) / 12);
+        if (cell_x != cell_x_new) {
+            int cell_y1 = (int)floor((e->y - 11) / 12), cell_y2 = (int)floor((e->y + 11) / 12);
+            if (!is_empty_column(S, cell_x, cell_y1, cell_y2, speed_dir)) { e->state = -1; return; }
+        }
+        e->x = xpos_new;
+    }
+    grid_move(S, e);
+}
+
+/* entity_boost_pad.py:46-64 */
+static void boost_move(OSim *S, Entity *e)
+{
+    Ninja *n = &S->nj;
+    if (!(n->state != 6 && n->state != 8 && n->state != 9)) { e->touching = 0; return; }
+    if (overlap_circle_vs_circle(e->x, e->y, e->radius, n->xpos, n->ypos, NINJA_RADIUS)) {
+        if (!e->touching) {
+            double vel_norm = sqrt(SQ(n->xspeed) + SQ(n->yspeed));
+            if (vel_norm > 0) {
+                double x_boost = 2 * n->xspeed / vel_norm;
+                double y_boost = 2 * n->yspeed / vel_norm;
+                n->xspeed += x_boost;
+                n->yspeed += y_boost;
+            }
+            e->touching = 1;
+        }
+    } else {
+        e->touching = 0;
+    }
+}
+
+/* entity_thwump.py:158-206 */
+static void thwump_think(OSim *S, Entity *e)
+{
+    Ninja *n = &S->nj;
+    if (e->state || !(n->state != 6 && n->state != 8 && n->state != 9)) return;
+    double activation_range = 2 * (9 + NINJA_RADIUS);
+    int i = 0;
+    if (!e->is_horizontal) {
+        if (fabs(e->x - n->xpos) < activation_range) {
+            int ninja_ycell = (int)floor(n->ypos / 12);
+            int thwump_ycell = (int)floor((e->y - e->direction * 11) / 12);
+            int thwump_xcell1 = (int)floor((e->x - 11) / 12), thwump_xcell2 = (int)floor((e->x + 11) / 12);
+            int dy = ninja_ycell - thwump_ycell;
+            if (dy * e->direction >= 0) {
+                for (i = 0; i < 100; i++) {
+                    if (!is_empty_row(S, thwump_xcell1, thwump_xcell2, thwump_ycell, e->direction)) {
+                        dy = ninja_ycell - thwump_ycell;
+                        break;
+                    }
+                    thwump_ycell += e->direction;
+                }
+                if (i == 100) i = 99;   /* Python leaves the loop variable at 99 when range(100) is exhausted */
+                if (i > 0 && dy * e->direction <= 0) e->state = 1;
+            }
+        }
+    } else {
+        if (fabs(e->y - n->ypos) < activation_range) {
+            int ninja_xcell = (int)floor(n->xpos / 12);
+            int thwump_xcell = (int)floor((e->x - e->direction * 11) / 12);
+            int thwump_ycell1 = (int)floor((e->y - 11) / 12), thwump_ycell2 = (int)floor((e->y + 11) / 12);
+            int dx = ninja_xcell - thwump_xcell;
+            if (dx * e->direction >= 0) {
+                for (i = 0; i < 100; i++) {
+                    if (!is_empty_column(S, thwump_xcell, thwump_ycell1, thwump_ycell2, e->direction)) {
+                        dx = ninja_xcell - thwump_xcell;
+                        break;
+                    }
+                    thwump_xcell += e->direction;
+                }
+                if (i == 100) i = 99;
+                if (i > 0 && dx * e->direction <= 0) e->state = 1;
+            }
+        }
+    }
+}
+
+/* entity_shove_thwump.py:127-153 */
+static void shove_move_if_possible(OSim *S, Entity *e, double xdir, double ydir, double speed)
+{
+    if (e->ydir == 0) {
+        double xpos_new = e->x + xdir * speed;
+        int cell_x = (int)floor(e->x / 12), cell_x_new = (int)floor(xpos_new / 12);
+        if (cell_x != cell_x_new) {
+            int cell_y1 = (int)floor((e->y - 8) / 12), cell_y2 = (int)floor((e->y + 8) / 12);
+            if (!is_empty_column(S, cell_x, cell_y1, cell_y2, (int)xdir)) { e->state = 3; return; }
+        }
+        e->x = xpos_new;
+    } else {
+        double ypos_new = e->y + ydir * speed;
+        int cell_y = (int)floor(e->y / 12), cell_y_new = (int)floor(ypos_new / 12);
+        if (cell_y != cell_y_new) {
+            int cell_x1 = (int)floor((e->x - 8) / 12), cell_x2 = (int)floor((e->x + 8) / 12);
+            if (!is_empty_row(S, cell_x1, cell_x2, cell_y, (int)ydir)) { e->state = 3; return; }
+        }
+        e->y = ypos_new;
+    }
+    grid_move(S, e);
+}
+
+/* entity_shove_thwump.py:109-125 */
+static void shove_think(OSim *S, Entity *e)
+{
+    if (e->state == 1) {
+        if (e->activated) { e->activated = 0; return; }
+        e->state = 2;
+    }
+    if (e->state == 3) {
+        double origin_dist = fabs(e->x - e->xorigin) + fabs(e->y - e->yorigin);
+        if (origin_dist >= 1) shove_move_if_possible(S, e, e->xdir, e->ydir, 1);
+        else { e->x = e->xorigin; e->y = e->yorigin; e->state = 0; }
+    } else if (e->state == 2) {
+        shove_move_if_possible(S, e, -e->xdir, -e->ydir, 4);
+    }
+}
+
+static double sweep_circle_vs_tiles(OSim *S, double xpos_old, double ypos_old, double dx, double dy, double radius);
+static int query_region(OSim *S, double x1, double y1, double x2, double y2, Seg **out);
+static int get_single_closest_point(double xpos, double ypos, double radius, Seg **segs, int n, double *oa, double *ob);
+
+/* entity_death_ball.py:74-167 */
+static void ball_think(OSim *S, Entity *e)
+{
+    Ninja *n = &S->nj;
+    if (!(n->state != 6 && n->state != 8 && n->state != 9)) {
+        e->xspeed *= 0.95;
+        e->yspeed *= 0.95;
+    } else {
+        double dx = n->xpos - e->x, dy = n->ypos - e->y;
+        double dist = sqrt(SQ(dx) + SQ(dy));
+        if (dist > 0) { dx /= dist; dy /= dist; }
+        e->xspeed += dx * 0.04;
+        e->yspeed += dy * 0.04;
+        double speed = sqrt(SQ(e->xspeed) + SQ(e->yspeed));
+        if (speed > 0.85) {
+            double new_speed = (speed - 0.85) * 0.9;
+            if (new_speed <= 0.01) new_speed = 0;
+            new_speed += 0.85;
+            e->xspeed = e->xspeed / speed * new_speed;
+            e->yspeed = e->yspeed / speed * new_speed;
+        }
+    }
+    double xpos_old = e->x, ypos_old = e->y;
+    e->x += e->xspeed;
+    e->y += e->yspeed;
+    double time = sweep_circle_vs_tiles(S, xpos_old, ypos_old, e->xspeed, e->yspeed, 8 * 0.5);
+    e->x = xpos_old + time * e->xspeed;
+    e->y = ypos_old + time * e->yspeed;
+    double xnormal = 0, ynormal = 0;
+    for (int it = 0; it < 16; it++) {
+        Seg *segs[MAXQ];
+        int nseg = query_region(S, e->x - 8, e->y - 8, e->x + 8, e->y + 8, segs);
+        double a = 0, b = 0;
+        int result = get_single_closest_point(e->x, e->y, 8, segs, nseg, &a, &b);
+        if (result == 0) break;
+        double dx = e->x - a, dy = e->y - b;
+        double dist = sqrt(SQ(dx) + SQ(dy));
+        double depen_len = 8 - dist * result;
+        if (depen_len < 0.0000001) break;
+        if (dist == 0) return;
+        double xnorm = dx / dist, ynorm = dy / dist;
+        e->x += xnorm * depen_len;
+        e->y += ynorm * depen_len;
+        xnormal += xnorm;
+        ynormal += ynorm;
+    }
+    double normal_len = sqrt(SQ(xnormal) + SQ(ynormal));
+    if (normal_len > 0) {
+        double dx = xnormal / normal_len, dy = ynormal / normal_len;
+        double dot_product = e->xspeed * dx + e->yspeed * dy;
+        if (dot_product < 0) {
+            double speed = sqrt(SQ(e->xspeed) + SQ(e->yspeed));
+            int bounce_strength = speed <= 1.35 ? 1 : 2;
+            e->xspeed -= dx * dot_product * bounce_strength;
+            e->yspeed -= dy * dot_product * bounce_strength;
+        }
+    }
+    /* :153-166.  Entity.index counts creations over the Simulator's lifetime (sim.entity_counts is never
+     * cleared), so the ball-ball repulsion only ever runs before the first Simulator.reset(). */
+    double db_count = S->nmap > 1200 ? S->map[1200] : 0;
+    int nballs = 0;
+    Entity *balls[64];
+    for (int i = 0; i < S->ndic; i++)
+        if (S->dic_order[i]->kind == K_BALL && nballs < 64) balls[nballs++] = S->dic_order[i];
+    int index = e->index + (S->creations - 1) * nballs;
+    if (index + 1 < db_count) {
+        for (int k = index + 1; k < nballs; k++) {
+            Entity *t = balls[k];
+            double dx = e->x - t->x, dy = e->y - t->y;
+            double dist = sqrt(SQ(dx) + SQ(dy));
+            if (dist < 16) {
+                dx = dx / dist * 4;
+                dy = dy / dist * 4;
+                e->xspeed += dx;
+                e->yspeed += dy;
+                t->xspeed -= dx;
+                t->yspeed -= dy;
+            }
+        }
+    }
+    grid_move(S, e);
+}
+
+/* entity_door_regular.py:46-53 */
+static void door_regular_think(OSim *S, Entity *e)
+{
+    if (!e->closed) {
+        e->open_timer += 1;
+        if (e->open_timer > 5) { e->closed = 1; door_edges_add(S, e, 1); }
+    }
+}
+
+/* entity_one_way_platform.py:79-105 */
+static int oneway_depen(const OSim *S, const Entity *e, double *len)
+{
+    const Ninja *n = &S->nj;
+    double dx = n->xpos - e->x, dy = n->ypos - e->y;
+    double lateral_dist = dy * e->nx - dx * e->ny;
+    double direction = (n->yspeed * e->nx - n->xspeed * e->ny) * lateral_dist;
+    double radius_scalar = direction < 0 ? 0.91 : 0.51;
+    if (fabs(lateral_dist) < radius_scalar * NINJA_RADIUS + 12) {
+        double normal_dist = dx * e->nx + dy * e->ny;
+        if (0 < normal_dist && normal_dist <= NINJA_RADIUS) {
+            double normal_proj = n->xspeed * e->nx + n->yspeed * e->ny;
+            if (normal_proj <= 0) {
+                double dx_old = n->xpos_old - e->x, dy_old = n->ypos_old - e->y;
+                double normal_dist_old = dx_old * e->nx + dy_old * e->ny;
+                if (NINJA_RADIUS - normal_dist_old <= 1.1) {
+                    *len = NINJA_RADIUS - normal_dist;
+                    return 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* physical_collision() of the four physically collidable kinds; 1 = (nx, ny), (len, len2) returned */
+static int entity_physical_collision(OSim *S, Entity *e, double *nx, double *ny, double *len)
+{
+    Ninja *n = &S->nj;
+    double len2;
+    switch (e->kind) {
+    case K_ONEWAY:
+        if (oneway_depen(S, e, len)) { *nx = e->nx; *ny = e->ny; return 1; }
+        return 0;
+    case K_BOUNCE: { /* entity_bounce_block.py:127-145 */
+        double dl;
+        if (!penetration_square_vs_point(e->x, e->y, n->xpos, n->ypos, 9 + NINJA_RADIUS, nx, ny, &dl, &len2)) return 0;
+        e->x -= *nx * dl * (1 - 0.2);
+        e->y -= *ny * dl * (1 - 0.2);
+        e->xspeed -= *nx * dl * (1 - 0.2);
+        e->yspeed -= *ny * dl * (1 - 0.2);
+        *len = dl * 0.2;
+        return 1;
+    }
+    case K_THWUMP: /* entity_thwump.py:208-213 */
+        return penetration_square_vs_point(e->x, e->y, n->xpos, n->ypos, 9 + NINJA_RADIUS, nx, ny, len, &len2);
+    case K_SHOVE: /* entity_shove_thwump.py:155-171 */
+        if (e->state <= 1) {
+            if (penetration_square_vs_point(e->x, e->y, n->xpos, n->ypos, 12 + NINJA_RADIUS, nx, ny, len, &len2)) {
+                if (e->state == 0 || e->xdir * *nx + e->ydir * *ny >= 0.01) return 1;
+            }
+        }
+        return 0;
+    default:
+        return 0;
+    }
+}
+
 /* entity_toggle_mine.py:90-118 */
 static void mine_think(OSim *S, Entity *e)
 {
@@ -706,9 +1325,12 @@ static void mine_think(OSim *S, Entity *e)
     }
 }
 
-static void entity_logical_collision(OSim *S, Entity *e)
+/* logical_collision() of every kind.  Returns 0 = None, 1 = a wall-normal contribution in *r0 (may be 0, which the
+ * caller's truth test drops like the reference's), 2 = launch pad boost (r0, r1). */
+static int entity_logical_collision(OSim *S, Entity *e, double *r0, double *r1)
 {
     Ninja *n = &S->nj;
+    double nx, ny, len, len2;
     switch (e->kind) {
     case K_MINE: /* entity_toggle_mine.py:120-128 */
         if (ninja_valid_target(n) && e->state == 0) {
@@ -740,10 +1362,99 @@ static void entity_logical_collision(OSim *S, Entity *e)
         if (overlap_circle_vs_circle(e->x, e->y, e->radius, n->xpos, n->ypos, NINJA_RADIUS)) {
             n->doors_opened += 1;
             e->closed = 0;
+            door_edges_add(S, e, -1);
             e->active = 0;
         }
         break;
+    case K_DOOR_REG: /* entity_door_regular.py:55-63: every overlapping frame decrements the edge counters again */
+        if (overlap_circle_vs_circle(e->x, e->y, e->radius, n->xpos, n->ypos, NINJA_RADIUS)) {
+            e->closed = 0;
+            door_edges_add(S, e, -1);
+            e->open_timer = 0;
+        }
+        break;
+    case K_DOOR_TRAP: /* entity_door_trap.py:60-67 */
+        if (overlap_circle_vs_circle(e->x, e->y, e->radius, n->xpos, n->ypos, NINJA_RADIUS)) {
+            e->closed = 1;
+            door_edges_add(S, e, 1);
+            e->active = 0;
+        }
+        break;
+    case K_LAUNCH: /* entity_launch_pad.py:82-100 */
+        if (ninja_valid_target(n)) {
+            if (overlap_circle_vs_circle(e->x, e->y, e->radius, n->xpos, n->ypos, NINJA_RADIUS)) {
+                if (((e->x - (n->xpos - NINJA_RADIUS * e->nx)) * e->nx + (e->y - (n->ypos - NINJA_RADIUS * e->ny)) * e->ny) >= -0.1) {
+                    double yboost_scale = 1;
+                    if (e->ny < 0) yboost_scale = 1 - e->ny;
+                    *r0 = e->nx * (36.0 / 7);
+                    *r1 = e->ny * (36.0 / 7) * yboost_scale;
+                    return 2;
+                }
+            }
+        }
+        break;
+    case K_ONEWAY: /* entity_one_way_platform.py:111-116 */
+        if (oneway_depen(S, e, &len)) {
+            if (fabs(e->nx) == 1) { *r0 = e->nx; return 1; }
+        }
+        break;
+    case K_DRONE: /* entity_drone_zap.py:57-64, entity_mini_drone.py:60-67 */
+        if (ninja_valid_target(n)) {
+            if (overlap_circle_vs_circle(e->x, e->y, e->drone_radius, n->xpos, n->ypos, NINJA_RADIUS)) ninja_kill(n, 3);
+        }
+        break;
+    case K_BOUNCE: /* entity_bounce_block.py:147-158 */
+        if (penetration_square_vs_point(e->x, e->y, n->xpos, n->ypos, 9 + NINJA_RADIUS + 0.1, &nx, &ny, &len, &len2)) {
+            *r0 = nx;
+            return 1;
+        }
+        break;
+    case K_THWUMP: /* entity_thwump.py:215-243 */
+        if (ninja_valid_target(n)) {
+            if (penetration_square_vs_point(e->x, e->y, n->xpos, n->ypos, 9 + NINJA_RADIUS + 0.1, &nx, &ny, &len, &len2)) {
+                double px1, py1, px2, py2;
+                if (e->is_horizontal) {
+                    double dx = (9 + 2) * e->direction, dy = 9 - 2;
+                    px1 = e->x + dx; py1 = e->y - dy; px2 = e->x + dx; py2 = e->y + dy;
+                } else {
+                    double dx = 9 - 2, dy = (9 + 2) * e->direction;
+                    px1 = e->x - dx; py1 = e->y + dy; px2 = e->x + dx; py2 = e->y + dy;
+                }
+                if (overlap_circle_vs_segment(n->xpos, n->ypos, NINJA_RADIUS + 2, px1, py1, px2, py2)) ninja_kill(n, 3);
+                *r0 = nx;
+                return 1;
+            }
+        }
+        break;
+    case K_BALL: /* entity_death_ball.py:169-181 */
+        if (ninja_valid_target(n)) {
+            if (overlap_circle_vs_circle(e->x, e->y, 5, n->xpos, n->ypos, NINJA_RADIUS)) {
+                double dx = e->x - n->xpos, dy = e->y - n->ypos;
+                double dist = sqrt(SQ(dx) + SQ(dy));
+                e->xspeed += dx / dist * 10;
+                e->yspeed += dy / dist * 10;
+                ninja_kill(n, 3);
+            }
+        }
+        break;
+    case K_SHOVE: { /* entity_shove_thwump.py:173-202 */
+        int depen = penetration_square_vs_point(e->x, e->y, n->xpos, n->ypos, 12 + NINJA_RADIUS + 0.1, &nx, &ny, &len, &len2);
+        if (depen && e->state <= 1) {
+            if (e->state == 0) {
+                e->activated = 1;
+                if (len2 > 0.2) { e->xdir = nx; e->ydir = ny; e->state = 1; }
+            } else {
+                if (e->xdir * nx + e->ydir * ny >= 0.01) e->activated = 1;
+                else return 0;
+            }
+            *r0 = nx;
+            return 1;
+        }
+        if (overlap_circle_vs_circle(n->xpos, n->ypos, NINJA_RADIUS, e->x, e->y, 8)) ninja_kill(n, 3);
+        break;
     }
+    }
+    return 0;
 }
 
 /* ninja.py:198-206 */
@@ -758,10 +1469,10 @@ static void ninja_integrate(Ninja *n)
     n->ypos += n->yspeed;
 }
 
-/* ninja.py:208-222 (the cached entity list only feeds physical collisions, ninja.py:224-267,
- * and none of the restated entity kinds is physically collidable) */
-static void ninja_pre_collision(Ninja *n)
+/* ninja.py:208-222 */
+static void ninja_pre_collision(OSim *S)
 {
+    Ninja *n = &S->nj;
     n->xspeed_old = n->xspeed;
     n->yspeed_old = n->yspeed;
     n->floor_count = n->wall_count = n->ceiling_count = 0;
@@ -770,6 +1481,48 @@ static void ninja_pre_collision(Ninja *n)
     n->is_crushable = 0;
     n->x_crush = n->y_crush = 0;
     n->crush_len = 0;
+    /* _cached_entities only feeds collide_vs_objects, which only looks at physically collidable entities */
+    S->ncached = S->has_zoo ? gather_entities(S, n->xpos, n->ypos, S->cached, 256) : 0;
+}
+
+/* ninja.py:224-267 */
+static void ninja_collide_vs_objects(OSim *S)
+{
+    Ninja *n = &S->nj;
+    for (int i = 0; i < S->ncached; i++) {
+        Entity *e = S->cached[i];
+        if (!e->physical) continue;
+        double depen_x, depen_y, depen_len;
+        if (!entity_physical_collision(S, e, &depen_x, &depen_y, &depen_len)) continue;
+        double pop_x = depen_x * depen_len, pop_y = depen_y * depen_len;
+        n->xpos += pop_x;
+        n->ypos += pop_y;
+        if (e->type != 17) {
+            n->x_crush += pop_x;
+            n->y_crush += pop_y;
+            n->crush_len += depen_len;
+        }
+        if (e->type == 20) n->is_crushable = 1;
+        if (e->type == 17 || e->type == 20 || e->type == 28) {
+            n->xspeed += pop_x;
+            n->yspeed += pop_y;
+        }
+        if (e->type == 11) {
+            double xspeed_new = (n->xspeed * depen_y - n->yspeed * depen_x) * depen_y;
+            double yspeed_new = (n->xspeed * depen_y - n->yspeed * depen_x) * (-depen_x);
+            n->xspeed = xspeed_new;
+            n->yspeed = yspeed_new;
+        }
+        if (depen_y >= -0.0001) {
+            n->ceiling_count += 1;
+            n->ceiling_normal_x += depen_x;
+            n->ceiling_normal_y += depen_y;
+        } else {
+            n->floor_count += 1;
+            n->floor_normal_x += depen_x;
+            n->floor_normal_y += depen_y;
+        }
+    }
 }
 
 /* ninja.py:269-379 */
@@ -838,8 +1591,28 @@ static void ninja_post_collision(OSim *S)
     double wall_normal = 0;
     Entity *near[256];
     int ne = gather_entities(S, n->xpos, n->ypos, near, 256);
-    for (int i = 0; i < ne; i++)
-        if (near[i]->logical) entity_logical_collision(S, near[i]);
+    for (int i = 0; i < ne; i++) {
+        if (!near[i]->logical) continue;
+        double r0 = 0, r1 = 0;
+        int kind = entity_logical_collision(S, near[i], &r0, &r1);
+        if (kind == 2) {   /* ninja.py:401-418: launch pad */
+            double xboost = r0 * 2 / 3, yboost = r1 * 2 / 3;
+            n->xpos += xboost;
+            n->ypos += yboost;
+            n->xspeed = xboost;
+            n->yspeed = yboost;
+            n->floor_count = 0;
+            n->floor_buffer = -1;
+            double boost_scalar = sqrt(SQ(xboost) + SQ(yboost));
+            n->xlp_boost_normalized = xboost / boost_scalar;
+            n->ylp_boost_normalized = yboost / boost_scalar;
+            n->launch_pad_buffer = 0;
+            if (n->state == 3) n->applied_gravity = GRAVITY_FALL;
+            n->state = 4;
+        } else if (kind == 1 && r0 != 0) {
+            wall_normal += r0;
+        }
+    }
 
     double rad = NINJA_RADIUS + 0.1;
     Seg *segs[MAXQ];
@@ -904,7 +1677,10 @@ static void ninja_post_collision(OSim *S)
             }
         }
     }
-    /* crush death (ninja.py:531-537) needs is_crushable, which only thwumps set */
+    /* ninja.py:531-537 */
+    if (n->is_crushable && n->crush_len > 0) {
+        if (sqrt(SQ(n->x_crush) + SQ(n->y_crush)) / n->crush_len < MIN_SURVIVABLE_CRUSHING) ninja_kill(n, 3);
+    }
 }
 
 /* ninja.py:539-579 */
@@ -1085,19 +1861,76 @@ void osim_tick(OSim *S, int hor_input, int jump_input)
     S->frame += 1;
     n->hor_input = hor_input;
     n->jump_input = jump_input;
-    for (int i = 0; i < S->ndic; i++) {
-        Entity *e = S->dic_order[i];
-        if (e->active && e->thinkable) mine_think(S, e);
+    if (!S->has_zoo) {
+        for (int i = 0; i < S->ndic; i++) {
+            Entity *e = S->dic_order[i];
+            if (e->active && e->thinkable) mine_think(S, e);
+        }
+    } else {
+        /* nsim.py:235-251: both lists are taken from the activity flags at the start of the tick */
+        unsigned char *mv = alloca(S->ndic), *th = alloca(S->ndic);
+        for (int i = 0; i < S->ndic; i++) {
+            Entity *e = S->dic_order[i];
+            mv[i] = e->active && e->movable;
+            th[i] = e->active && e->thinkable;
+        }
+        for (int i = 0; i < S->ndic; i++) {
+            if (!mv[i]) continue;
+            Entity *e = S->dic_order[i];
+            switch (e->kind) {
+            case K_DRONE: drone_move(S, e); break;
+            case K_BOUNCE: bounce_move(S, e); break;
+            case K_THWUMP: thwump_move(S, e); break;
+            case K_BOOST: boost_move(S, e); break;
+            default: break;
+            }
+        }
+        for (int i = 0; i < S->ndic; i++) {
+            if (!th[i]) continue;
+            Entity *e = S->dic_order[i];
+            switch (e->kind) {
+            case K_MINE: mine_think(S, e); break;
+            case K_DOOR_REG: door_regular_think(S, e); break;
+            case K_THWUMP: thwump_think(S, e); break;
+            case K_BALL: ball_think(S, e); break;
+            case K_SHOVE: shove_think(S, e); break;
+            default: break;
+            }
+        }
     }
     if (n->state != 9) {
         if (n->state != 6) {   /* state 6 -> ragdoll, which is None without the animation file */
             ninja_integrate(n);
-            ninja_pre_collision(n);
-            for (int k = 0; k < 4; k++) ninja_collide_vs_tiles(S);   /* collide_vs_objects is a no-op here */
+            ninja_pre_collision(S);
+            for (int k = 0; k < 4; k++) {
+                ninja_collide_vs_objects(S);
+                ninja_collide_vs_tiles(S);
+            }
             ninja_post_collision(S);
         }
         ninja_think(n);
     }
+}
+
+/* entity checksum of tests/golden/make_golden_zoo.py:ent_row (entity_dic order) */
+void osim_entity_checksum(const OSim *S, double *out)
+{
+    double sx = 0, sy = 0, svx = 0, svy = 0;
+    long code = 0, act = 0;
+    for (int i = 0; i < S->ndic; i++) {
+        const Entity *e = S->dic_order[i];
+        sx += e->x; sy += e->y;
+        if (e->kind == K_BOUNCE || e->kind == K_BALL) { svx += e->xspeed; svy += e->yspeed; }
+        int c = 0;
+        if (e->kind == K_LOCKED || e->kind == K_DOOR_REG || e->kind == K_DOOR_TRAP) c += 3 * e->closed;
+        if (e->kind == K_MINE || e->kind == K_THWUMP || e->kind == K_SHOVE) c += 5 * (((e->state % 7) + 7) % 7);
+        if (e->kind == K_DRONE) c += 11 * e->dir;
+        if (e->kind == K_BOOST) c += 13 * e->touching;
+        if (e->kind == K_SHOVE) c += 17 * e->activated;
+        code += c;
+        act += e->active;
+    }
+    out[0] = sx; out[1] = sy; out[2] = svx; out[3] = svy; out[4] = (double)code; out[5] = (double)act;
 }
 
 /* ------------------------------------------------------------------------------------

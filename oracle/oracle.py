@@ -62,6 +62,7 @@ def _lib(variant):
     lib.osim_dump_entities.restype = C.c_int
     lib.osim_entity_states.argtypes = [P, C.POINTER(C.c_int), C.c_int]
     lib.osim_entity_states.restype = C.c_int
+    lib.osim_entity_checksum.argtypes = [P, C.POINTER(C.c_double)]
     lib.osim_env_step.argtypes = [P, C.c_int, C.c_int, C.POINTER(C.c_int)]
     lib.osim_env_step.restype = C.c_int
     lib.osim_run_batch.argtypes = [C.POINTER(P), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int]
@@ -137,6 +138,11 @@ class Oracle:
         n = self.lib.osim_dump_entities(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), len(buf))
         assert n >= 0
         return buf[:n].copy()
+
+    def entity_checksum(self):
+        o = np.zeros(6, dtype=np.float64)
+        self.lib.osim_entity_checksum(self.h, o.ctypes.data_as(C.POINTER(C.c_double)))
+        return o
 
     def entity_states(self):
         buf = np.zeros(4096, dtype=np.int32)
