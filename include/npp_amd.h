@@ -148,6 +148,12 @@ int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int m
                                uint32_t *unsupported_mask);
 int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out);
 
+/* Test / debug aid for levels with moving entities: per env 6 doubles summed over the entities in the reference's
+ * entity_dic order (keys ascending, creation order inside a key): sum x, sum y, sum xspeed, sum yspeed (bounce blocks and
+ * death balls), sum of state codes (3*closed + 5*(state mod 7) + 11*dir + 13*touching + 17*activated), number of active
+ * entities -- the row tests/golden/make_golden_zoo.py records from the reference after every tick. */
+int npp_entity_checksum(npp_handle h, int env0, int count, double *out);
+
 /* Go-Explore style checkpoints (state_checkpoint.py / action_replayer.py in the reference restore a state by
  * reset + replaying the action sequence and validating |dpos| < 0.01 px).  Here a checkpoint is a raw copy of the
  * SoA state of ALL envs kept on the device (one slot per handle): npp_snapshot stores it, npp_restore puts it back for

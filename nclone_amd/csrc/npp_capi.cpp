@@ -22,6 +22,10 @@ struct npp_handle_s {
     uint32_t *d_u32 = nullptr;
     uint32_t *d_ent = nullptr;
     float *d_sc_cache = nullptr;
+    double *d_zoo = nullptr;   // per-env zoo blocks (NULL unless a loaded level has zoo entities)
+    double *s_zoo = nullptr;
+    int zoo_words = 0, zoo_doors = 0, zoo_movers = 0;
+    int zoo_active = 0;        // some env is assigned a level with zoo entities
     // snapshot slot (npp_snapshot / npp_restore)
     double *s_f64 = nullptr;
     uint32_t *s_u32 = nullptr;
@@ -84,17 +88,22 @@ void plan_geometry(npp_handle h) {
     if (wpb <= 0) wpb = 4;
     if (wpb > 4) wpb = 4;
     while (wpb > 1 && (64 / g) * wpb > h->n) wpb >>= 1;
-    // LDS plan: staged level + entity words + observation staging must fit the per-workgroup budget
+    h->zoo_active = 0;
+    if (h->d_zoo)
+        for (int e = 0; e < h->n && !h->zoo_active; e++) h->zoo_active = h->levels[h->env_level[e]].has_zoo ? 1 : 0;
+    const int zw = h->zoo_active ? h->zoo_words : 0;
+    // LDS plan: staged level + entity words + observation staging (+ zoo blocks) must fit the per-workgroup budget
     for (;;) {
         int epb = (64 / g) * wpb;
-        uint32_t fixed = (uint32_t)h->n_words_max * epb * 4 + (uint32_t)epb * 41 * 4;
+        uint32_t fixed = (uint32_t)lds_bytes(0, h->n_words_max, epb, zw);
+        if (fixed > LDS_BUDGET) {
+            if (wpb > 1) { wpb >>= 1; continue; }
+            if (g < 64) { g *= 2; continue; }   // zoo blocks are big: fewer envs per wavefront
+        }
         uint32_t cap = h->hot_max;
         if (fixed + cap > LDS_BUDGET) cap = fixed < LDS_BUDGET ? ((LDS_BUDGET - fixed) / 16) * 16 : 0;
-        if (fixed + cap <= LDS_BUDGET || wpb == 1) {
-            h->lds_hot_cap = cap;
-            break;
-        }
-        wpb >>= 1;
+        h->lds_hot_cap = cap;
+        break;
     }
     h->geo_g = g;
     h->geo_wpb = wpb;
@@ -128,6 +137,11 @@ KernelArgs base_args(npp_handle h) {
     a.lanes_per_env = h->geo_g;
     a.waves_per_block = h->geo_wpb;
     a.lds_level = h->lds_level;
+    a.zoo = h->d_zoo;
+    a.zoo_words = h->zoo_words;
+    a.zoo_doors = h->zoo_doors;
+    a.zoo_movers = h->zoo_movers;
+    a.zoo_active = h->zoo_active;
     return a;
 }
 
@@ -141,6 +155,23 @@ void fill_out(KernelArgs &a, const npp_step_out *o) {
     a.out.frames = o->d_frames;
     a.out.terminal_state = o->d_terminal_state;
     a.out.spatial_context = o->d_spatial_context;
+}
+
+// `fresh` = the entities are created for the first time since the level was assigned (the state a replay starts from);
+// any later reset is a Simulator.reset(), after which Entity.index no longer starts at 0 (see ZOO_HEAD in npp_internal.hpp)
+int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh) {
+    if (!h) return NPP_ERR_INVALID;
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reset: no levels loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    KernelArgs a = base_args(h);
+    a.reset_fresh = fresh;
+    if (env_mask) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        a.reset_mask = h->d_mask;
+    }
+    HIP_TRY(h, launch_reset(a, h->stream));
+    if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));  // env_mask is caller memory: finish the copy
+    return NPP_OK;
 }
 
 }  // namespace
@@ -186,7 +217,7 @@ int npp_destroy(npp_handle h) {
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache);
-    hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc);
+    hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
     return NPP_OK;
 }
@@ -223,6 +254,10 @@ int npp_snapshot(npp_handle h) {
     HIP_TRY(h, hipMemcpyAsync(h->s_u32, h->d_u32, sizeof(uint32_t) * NU32 * N, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->s_ent, h->d_ent, sizeof(uint32_t) * (size_t)h->n_words_max * N, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->s_sc, h->d_sc_cache, sizeof(float) * 48 * N, hipMemcpyDeviceToDevice, h->stream));
+    if (h->d_zoo) {
+        if (!h->s_zoo) HIP_TRY(h, hipMalloc((void **)&h->s_zoo, sizeof(double) * (size_t)h->zoo_words * N));
+        HIP_TRY(h, hipMemcpyAsync(h->s_zoo, h->d_zoo, sizeof(double) * (size_t)h->zoo_words * N, hipMemcpyDeviceToDevice, h->stream));
+    }
     h->s_gen = h->assign_gen;
     return NPP_OK;
 }
@@ -237,7 +272,7 @@ int npp_restore(npp_handle h, const uint8_t *env_mask) {
         HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
         a.reset_mask = h->d_mask;
     }
-    HIP_TRY(h, launch_restore(a, h->s_f64, h->s_u32, h->s_ent, h->s_sc, h->stream));
+    HIP_TRY(h, launch_restore(a, h->s_f64, h->s_u32, h->s_ent, h->s_sc, h->d_zoo ? h->s_zoo : nullptr, h->stream));
     if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NPP_OK;
 }
@@ -283,6 +318,8 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     std::vector<LevelHdr> hdrs(n_levels);
     int words_max = 1;
     uint32_t hot_max = 0;
+    bool any_zoo = false;
+    int zoo_doors = 0, zoo_movers = 0;
     auto append = [&](const void *p, size_t bytes, uint32_t align) -> uint32_t {
         uint32_t off = align_up((uint32_t)host.size(), align);
         host.resize(off + bytes);
@@ -309,6 +346,24 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.off_raster = append(L.raster_order.data(), 2 * L.raster_order.size(), 4);
         H.off_doors = append(L.door_segs.data(), 8 * L.door_segs.size(), 8);
         H.n_door = (uint32_t)(L.door_segs.size() / 5);
+        H.has_zoo = L.has_zoo ? 1u : 0u;
+        H.off_ent_seq = append(L.ent_seq.data(), 2 * L.ent_seq.size(), 4);
+        H.off_ent_cell = append(L.ent_cell.data(), 2 * L.ent_cell.size(), 4);
+        H.off_mov_meta = append(L.mov_meta.data(), 4 * L.mov_meta.size(), 4);
+        H.off_mov_x0 = append(L.mov_x0.data(), 8 * L.mov_x0.size(), 8);
+        H.off_mov_y0 = append(L.mov_y0.data(), 8 * L.mov_y0.size(), 8);
+        H.off_edges = append(L.edges.data(), 4 * L.edges.size(), 8);
+        H.off_door_tab = append(L.door_tab.data(), 4 * L.door_tab.size(), 4);
+        H.n_mov = (uint32_t)L.mov_meta.size();
+        H.n_zdoor = (uint32_t)(L.door_tab.size() / 2);
+        H.n_created = (uint32_t)L.n_created;
+        H.n_balls = (uint32_t)L.n_balls;
+        H.db_count = L.db_count;
+        if (L.has_zoo) {
+            any_zoo = true;
+            zoo_doors = std::max(zoo_doors, (int)H.n_zdoor);
+            zoo_movers = std::max(zoo_movers, (int)H.n_mov);
+        }
         H.n_seg = (uint32_t)L.segs.size();
         H.n_ent = (uint32_t)L.ent_x.size();
         H.n_words = (uint32_t)L.ent_init_words.size();
@@ -329,6 +384,15 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     hipFree(h->d_blob); h->d_blob = nullptr;
     hipFree(h->d_hdr); h->d_hdr = nullptr;
     hipFree(h->d_ent); h->d_ent = nullptr;
+    hipFree(h->d_zoo); h->d_zoo = nullptr;
+    hipFree(h->s_zoo); h->s_zoo = nullptr;
+    h->zoo_words = any_zoo ? zoo_words_for(zoo_doors, zoo_movers) : 0;
+    h->zoo_doors = zoo_doors;
+    h->zoo_movers = zoo_movers;
+    if (any_zoo) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_zoo, sizeof(double) * (size_t)h->zoo_words * h->n));
+        HIP_TRY(h, hipMemset(h->d_zoo, 0, sizeof(double) * (size_t)h->zoo_words * h->n));
+    }
     HIP_TRY(h, hipMalloc((void **)&h->d_blob, host.size() + 16));
     HIP_TRY(h, hipMemcpy(h->d_blob, host.data(), host.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMalloc((void **)&h->d_hdr, sizeof(LevelHdr) * n_levels));
@@ -342,11 +406,11 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     h->hot_max = hot_max;
     std::fill(h->env_level.begin(), h->env_level.end(), 0);
     plan_geometry(h);
-    if (lds_bytes(h->lds_hot_cap, h->n_words_max, (64 / h->geo_g) * h->geo_wpb) > 160 * 1024)
+    if (lds_bytes(h->lds_hot_cap, h->n_words_max, (64 / h->geo_g) * h->geo_wpb, h->zoo_active ? h->zoo_words : 0) > LDS_BUDGET)
         return fail(h, NPP_ERR_INVALID, "npp_load_levels: entity tables exceed LDS");
     std::fill(h->env_level.begin(), h->env_level.end(), 0);
     HIP_TRY(h, hipMemset(h->d_env_level, 0, sizeof(int32_t) * (size_t)h->n));
-    return npp_reset(h, nullptr);
+    return reset_impl(h, nullptr, 1);
 }
 
 int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level_ids, int n) {
@@ -366,22 +430,10 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_env_level, h->env_level.data(), sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
-    return npp_reset(h, mask.data());
+    return reset_impl(h, mask.data(), 1);
 }
 
-int npp_reset(npp_handle h, const uint8_t *env_mask) {
-    if (!h) return NPP_ERR_INVALID;
-    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reset: no levels loaded");
-    HIP_TRY(h, hipSetDevice(h->device));
-    KernelArgs a = base_args(h);
-    if (env_mask) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
-        a.reset_mask = h->d_mask;
-    }
-    HIP_TRY(h, launch_reset(a, h->stream));
-    if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));  // env_mask is caller memory: finish the copy
-    return NPP_OK;
-}
+int npp_reset(npp_handle h, const uint8_t *env_mask) { return reset_impl(h, env_mask, 0); }
 
 int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
     if (!h) return NPP_ERR_INVALID;
@@ -501,6 +553,61 @@ int npp_dump_entities(npp_handle h, int env, int32_t *out, int max, int *n_out) 
         out[i] = (w[slot >> 4] >> ((slot & 15) * 2)) & 3;
     }
     *n_out = n;
+    return NPP_OK;
+}
+
+int npp_entity_checksum(npp_handle h, int env0, int count, double *out) {
+    if (!h || env0 < 0 || count <= 0 || env0 + count > h->n || !out) return fail(h, NPP_ERR_INVALID, "npp_entity_checksum: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_entity_checksum: no levels loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    size_t N = (size_t)h->n;
+    std::vector<uint32_t> w((size_t)h->n_words_max * count);
+    for (int k = 0; k < h->n_words_max; k++)
+        HIP_TRY(h, hipMemcpy(w.data() + (size_t)k * count, h->d_ent + k * N + env0, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+    std::vector<double> zb;
+    if (h->d_zoo) {
+        zb.resize((size_t)h->zoo_words * count);
+        HIP_TRY(h, hipMemcpy(zb.data(), h->d_zoo + (size_t)env0 * h->zoo_words, sizeof(double) * zb.size(), hipMemcpyDeviceToHost));
+    }
+    const int door_words = (h->zoo_doors + 1) / 2;
+    for (int i = 0; i < count; i++) {
+        const CompiledLevel &L = h->levels[h->env_level[env0 + i]];
+        const double *blk = L.has_zoo && h->d_zoo ? zb.data() + (size_t)i * h->zoo_words : nullptr;
+        double sx = 0, sy = 0, svx = 0, svy = 0;
+        long code = 0, act = 0;
+        for (uint32_t ref : L.dic_order) {
+            if (ref & 0x80000000u) {
+                int m = (int)(ref & 0x7fffffffu);
+                uint32_t kind = L.mov_meta[m] & 7u;
+                if (!blk) { sx += L.mov_x0[m]; sy += L.mov_y0[m]; act += 1; continue; }
+                const double *p = blk + ZOO_HEAD + door_words + ZOO_MOV_WORDS * m;
+                uint64_t wd;
+                std::memcpy(&wd, p + 4, 8);
+                uint32_t w0 = (uint32_t)wd;
+                sx += p[0]; sy += p[1];
+                if (kind == MK_BOUNCE || kind == MK_BALL) { svx += p[2]; svy += p[3]; }
+                if (kind == MK_DRONE || kind == MK_MINI) code += 11 * ((w0 >> 11) & 3u);
+                if (kind == MK_THWUMP) code += 5 * (((int)((w0 >> 11) & 3u) - 1 + 7) % 7);
+                if (kind == MK_SHOVE) code += 5 * ((w0 >> 11) & 3u) + 17 * ((w0 >> 13) & 1u);
+                act += 1;
+            } else {
+                int s = (int)ref;
+                uint32_t kind = L.ent_meta[s] & 15u;
+                uint32_t st = (w[(size_t)(s >> 4) * count + i] >> ((s & 15) * 2)) & 3u;
+                sx += L.ent_x[s]; sy += L.ent_y[s];
+                if (kind == EK_MINE) { code += 5 * st; act += 1; }
+                else if (kind == EK_EXIT) act += 1;                       // the door object itself never deactivates
+                else if (kind == EK_LOCKED) { code += 3 * (st & 1u); act += st & 1u; }
+                else if (kind == EK_DOOR_REG) { code += 3 * ((st >> 1) & 1u); act += 1; }
+                else if (kind == EK_DOOR_TRAP) { code += 3 * (1u - (st & 1u)); act += st & 1u; }
+                else if (kind == EK_BOOST) { code += 13 * ((st >> 1) & 1u); act += 1; }
+                else act += st & 1u;
+            }
+        }
+        double *o = out + (size_t)i * 6;
+        o[0] = sx; o[1] = sy; o[2] = svx; o[3] = svy; o[4] = (double)code; o[5] = (double)act;
+    }
     return NPP_OK;
 }
 

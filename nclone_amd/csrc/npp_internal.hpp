@@ -32,6 +32,20 @@ struct LevelHdr {
     int32_t obs_switch;
     int32_t obs_door;
     uint32_t fits_lds;
+    // entity zoo (all zero / unused when has_zoo == 0)
+    uint32_t has_zoo;
+    uint32_t off_ent_seq;   // u16[n_ent]
+    uint32_t off_ent_cell;  // u16[n_ent]
+    uint32_t off_mov_meta;  // u32[n_mov]
+    uint32_t off_mov_x0;    // f64[n_mov]
+    uint32_t off_mov_y0;    // f64[n_mov]
+    uint32_t off_edges;     // u32[2 * EDGE_WORDS]
+    uint32_t off_door_tab;  // u32[2 * n_zdoor]
+    uint32_t n_mov;
+    uint32_t n_zdoor;
+    uint32_t n_created;
+    uint32_t n_balls;
+    double db_count;
     double spawn_x, spawn_y;
     double sw_x, sw_y, door_x, door_y;
 };
@@ -73,23 +87,45 @@ struct KernelArgs {
     int waves_per_block;  // WPB
     uint32_t lds_hot_cap; // bytes reserved for a staged level
     int lds_level;        // 1: every workgroup is level-uniform and its level fits lds_hot_cap -> stage it in LDS
+    // entity zoo: per-env block of zoo_words 8-byte words at zoo[env * zoo_words] (layout: ZOO_* below); NULL when no
+    // loaded level has zoo entities (then the plain kernels run)
+    double *zoo;
+    int zoo_words;
+    int zoo_doors;        // door slots per env (max over levels)
+    int zoo_movers;       // mover slots per env (max over levels)
+    int zoo_active;       // 1: some env currently plays a level with zoo entities -> the zoo step kernel runs
+    int reset_fresh;      // reset kernel: 1 = this reset is the first creation after a (re)assignment of levels
     StepOut out;
 };
 
 constexpr int WAVE = 64;
 
+// per-env zoo block, in 8-byte words: [0] xlp_boost_normalized, [1] ylp_boost_normalized, [2] lo32 = next list-order
+// number (grid_move appends), hi32 = 1 while the entities are in their first creation since the level was assigned
+// (Entity.index bug-compat, see entity_death_ball.py:153-166), then ceil(zoo_doors / 2) words of i32 door state
+// (low 16 bits signed edge counter, bits 16-23 open_timer), then 5 words per mover: x, y, a, b, lo32 = cell | bits << 11,
+// hi32 = list-order number.
+constexpr int ZOO_HEAD = 3;
+constexpr int ZOO_MOV_WORDS = 5;
+inline int zoo_words_for(int doors, int movers) { return ZOO_HEAD + (doors + 1) / 2 + ZOO_MOV_WORDS * movers; }
+constexpr int EDGE_WORDS_D = 142;   // == npp::EDGE_WORDS (npp_level.hpp)
+
 // Launch geometry: G lanes cooperate on one environment (G in {1,2,4,8,16,32,64}); a wavefront holds 64/G envs; a
 // workgroup holds WPB wavefronts that share one LDS copy of a level when all their envs play the same level.
 // dynamic LDS layout: [hot_cap][ent words: n_words_max * envs_per_block * 4][obs staging: envs_per_block * 41 * 4]
-inline size_t lds_bytes(uint32_t hot_cap, int n_words_max, int envs_per_block) {
-    return (size_t)hot_cap + (size_t)n_words_max * envs_per_block * 4 + (size_t)envs_per_block * 41 * 4;
+inline size_t lds_bytes(uint32_t hot_cap, int n_words_max, int envs_per_block, int zoo_words = 0) {
+    size_t b = (size_t)hot_cap + (size_t)n_words_max * envs_per_block * 4 + (size_t)envs_per_block * 41 * 4;
+    b = (b + 7) & ~(size_t)7;
+    // zoo kernels add, per env: the zoo block and a private copy of the level's grid-edge bitmaps
+    if (zoo_words) b += (size_t)envs_per_block * ((size_t)zoo_words * 8 + 2 * EDGE_WORDS_D * 4);
+    return b;
 }
 
 hipError_t launch_step(const KernelArgs &a, hipStream_t s);
 hipError_t launch_reset(const KernelArgs &a, hipStream_t s);
 // per-env copy of every state plane from `src` into the live state (a.reset_mask selects envs; NULL = all)
 hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint32_t *src_u32, const uint32_t *src_ent,
-                          const float *src_sc, hipStream_t s);
+                          const float *src_sc, const double *src_zoo, hipStream_t s);
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
 
 }  // namespace npp

@@ -651,6 +651,7 @@ DEV double rcp_inrange(double b) {
 // fallback.  CLOSEST(m) fills `m` with the lane's best candidate; everything else is identical.
 struct DepenIO {
     double x, y, vx, vy, fnsx, fnsy, cnsx, cnsy;
+    double xcr, ycr, clen;   // crush accumulators (ninja.py:344-346); dead code unless a thwump can crush (zoo levels)
     int fcount, ccount, applied;
 };
 
@@ -673,8 +674,10 @@ struct DepenIO {
         (io).applied = 1;                                                                              \
         double inv_dist = rcp_inrange(dist);                                                           \
         double norm_dx = ddx * inv_dist, norm_dy = ddy * inv_dist;                                     \
-        (io).x += norm_dx * depen_len;                                                                 \
-        (io).y += norm_dy * depen_len;                                                                 \
+        const double depen_x = norm_dx * depen_len, depen_y = norm_dy * depen_len;                     \
+        (io).x += depen_x;                                                                             \
+        (io).y += depen_y;                                                                             \
+        (io).xcr += depen_x; (io).ycr += depen_y; (io).clen += depen_len;                              \
         double dot_product = (io).vx * ddx + (io).vy * ddy;                                            \
         if (dot_product < 0) {                                                                         \
             double cross_product = (io).vx * ddy - (io).vy * ddx;                                      \
@@ -719,9 +722,10 @@ __device__ __noinline__ DepenIO depen_generic(TileRefs lv, int r, double gx0, do
 }
 
 // Ninja.collide_vs_tiles (ninja.py:269-379).  Returns true when at least one depenetration was applied.
+struct Crush { double xcr, ycr, clen; };
 template <int G, int K>
 DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double xold, double yold, double &fnsx, double &fnsy,
-                          double &cnsx, double &cnsy STAMP_ARG) {
+                          double &cnsx, double &cnsy, Crush &cr STAMP_ARG) {
     double dx = n.x - xold, dy = n.y - yold;
     // ---- sweep_circle_vs_tiles (physics.py:104-128); the early `return 0` of the reference equals the minimum
     double time = 1;
@@ -767,6 +771,7 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
     io.x = n.x; io.y = n.y; io.vx = n.vx; io.vy = n.vy;
     io.fnsx = fnsx; io.fnsy = fnsy; io.cnsx = cnsx; io.cnsy = cnsy;
     io.fcount = n.fcount; io.ccount = n.ccount; io.applied = 0;
+    io.xcr = cr.xcr; io.ycr = cr.ycr; io.clen = cr.clen;
     STAMP(9);   // sweep + gather setup
     if (fast) {
         for (int it = 0; it < 32; it++) {
@@ -804,6 +809,7 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
     n.x = io.x; n.y = io.y; n.vx = io.vx; n.vy = io.vy;
     fnsx = io.fnsx; fnsy = io.fnsy; cnsx = io.cnsx; cnsy = io.cnsy;
     n.fcount = io.fcount; n.ccount = io.ccount;
+    cr.xcr = io.xcr; cr.ycr = io.ycr; cr.clen = io.clen;
     return io.applied != 0;
 }
 
@@ -918,10 +924,9 @@ DEV double wall_term(double px, double py, double a, double b, double rad) {
 
 template <int G>
 __device__ __noinline__ double wall_probe_generic(TileRefs lv, int r, double px, double py, double qx0, double qy0,
-                                                  double qx1, double qy1) {
+                                                  double qx1, double qy1, double wall_normal) {
     const double rad = NINJA_RADIUS + 0.1;
     const int c0x = cell_coord(qx0, 43), c1x = cell_coord(qx1, 43), c0y = cell_coord(qy0, 24), c1y = cell_coord(qy1, 24);
-    double wall_normal = 0;
     for (int xc = c0x; xc <= c1x; xc++) {
         int i0 = lv.seg_start[xc * 25 + c0y], i1 = lv.seg_start[xc * 25 + c1y + 1];
         for (int ib = i0; ib < i1; ib += G) {   // group-uniform trip count
@@ -942,12 +947,16 @@ __device__ __noinline__ double wall_probe_generic(TileRefs lv, int r, double px,
     return wall_normal;
 }
 
+#include "npp_zoo.hpp"
+
 // Ninja.post_collision (ninja.py:381-537)
-template <int G, int K>
-DEV void post_collision(const Lv &lv, int r, Nj &n, const Cand<K> &cd, EntBits eb, double fnsx, double fnsy, double cnsx, double cnsy) {
-    logical_collisions(lv, n, eb);
-    // wall probe (ninja.py:424-441): terms summed in query order
+template <int G, int K, bool ZOO>
+DEV void post_collision(const Lv &lv, const Zoo &z, int r, Nj &n, const Cand<K> &cd, EntBits eb, double fnsx, double fnsy,
+                        double cnsx, double cnsy, double xold, double yold, const ZTick &zt) {
+    // wall probe (ninja.py:424-441): entity contributions first (ninja.py:397-420), then tile terms in query order
     double wall_normal = 0;
+    if (ZOO && z.on) wall_normal = logical_collisions_zoo<G>(lv, z, r, n, eb, xold, yold);
+    else logical_collisions(lv, n, eb);
     const double rad = NINJA_RADIUS + 0.1;
     double qx0 = n.x - rad, qy0 = n.y - rad, qx1 = n.x + rad, qy1 = n.y + rad;
     const QBox q = make_qbox(qx0, qy0, qx1, qy1);
@@ -964,7 +973,7 @@ DEV void post_collision(const Lv &lv, int r, Nj &n, const Cand<K> &cd, EntBits e
             if (group_any<G>(term != 0)) ordered_add<G>(wall_normal, term);
         }
     } else {
-        wall_normal = wall_probe_generic<G>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, n.x, n.y, qx0, qy0, qx1, qy1);
+        wall_normal = wall_probe_generic<G>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, n.x, n.y, qx0, qy0, qx1, qy1, wall_normal);
     }
     n.airborn_old = n.airborn;
     n.airborn = 1;
@@ -998,6 +1007,7 @@ DEV void post_collision(const Lv &lv, int r, Nj &n, const Cand<K> &cd, EntBits e
             }
         }
     }
+    if (ZOO && z.on) zoo_crush_check(n, zt);
 }
 
 DEV void floor_jump(Nj &n) {   // ninja.py:539-579
@@ -1035,12 +1045,13 @@ DEV void wall_jump(Nj &n) {    // ninja.py:581-608
     n.jdur = 0;
 }
 
-// Ninja.think (ninja.py:849-1059)
-DEV void ninja_think(Nj &n) {
+// Ninja.think (ninja.py:849-1059); lp = launch pad boost direction (xlp/ylp_boost_normalized) on zoo levels, else NULL
+DEV void ninja_think(Nj &n, const double *lp) {
     if (n.state != n.pstate) { n.scf = 0; n.pstate = n.state; } else { n.scf += 1; }
     bool new_jump_check = n.jump ? (n.jio == 0) : false;
     n.jio = n.jump;
     n.lbuf = (-1 < n.lbuf && n.lbuf < 3) ? n.lbuf + 1 : -1;
+    const bool in_lp_buffer = -1 < n.lbuf && n.lbuf < 4;
     n.jbuf = (-1 < n.jbuf && n.jbuf < 5) ? n.jbuf + 1 : -1;
     bool in_jump_buffer = -1 < n.jbuf && n.jbuf < 5;
     n.wbuf = (-1 < n.wbuf && n.wbuf < 5) ? n.wbuf + 1 : -1;
@@ -1111,7 +1122,14 @@ DEV void ninja_think(Nj &n) {
     if (in_jump_buffer || new_jump_check) {
         if (n.walled || in_wall_buffer) { wall_jump(n); return; }
         if (in_floor_buffer) { floor_jump(n); return; }
-        // launch-pad jump (ninja.py:1043-1045) needs a launch pad, which the accelerated path does not simulate
+        if (lp && in_lp_buffer && new_jump_check) {   // lp_jump (ninja.py:610-626, 1043-1045)
+            n.fbuf = -1; n.wbuf = -1; n.jbuf = -1; n.lbuf = -1;
+            double boost_scalar = 2 * dabs(lp[0]) + 2;
+            if (boost_scalar == 2) boost_scalar = 1.7;
+            n.vx += lp[0] * boost_scalar * TWO_THIRDS;
+            n.vy += lp[1] * boost_scalar * TWO_THIRDS;
+            return;
+        }
     }
     if (!n.walled) {
         if (n.state == 5) n.state = 4;
@@ -1125,14 +1143,16 @@ DEV void ninja_think(Nj &n) {
 }
 
 // Simulator.tick (nsim.py:221-292)
-template <int G>
-DEV void sim_tick(const Lv &lv, int r, Nj &n, EntBits eb, int hor, int jump STAMP_ARG) {
+template <int G, bool ZOO>
+DEV void sim_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb, int hor, int jump, int n_ent STAMP_ARG) {
     constexpr int K = KSlots<G>::value;
     STAMP_INIT;
     n.frame += 1;
     n.hor = hor;
     n.jump = jump;
-    think_mines(lv, n, eb);
+    const bool zoo = ZOO && z.on;
+    if (zoo) zoo_entities_tick<G>(lv, z, r, n, eb, n_ent);
+    else think_mines(lv, n, eb);
     STAMP(2);
     if (n.state == 9) return;
     if (n.state != 6) {
@@ -1148,6 +1168,9 @@ DEV void sim_tick(const Lv &lv, int r, Nj &n, EntBits eb, int hor, int jump STAM
         n.vxo = n.vx; n.vyo = n.vy;
         n.fcount = 0; n.ccount = 0;
         double fnsx = 0, fnsy = 0, cnsx = 0, cnsy = 0;
+        ZTick zt;
+        zt.xcr = 0; zt.ycr = 0; zt.clen = 0; zt.crushable = 0; zt.gcx = 0; zt.gcy = 0; zt.phys_near = false;
+        if (zoo) zoo_pre_collision<G>(lv, z, r, n, zt);
         // candidate segments for every query of this tick: cells touched by the path inflated by the largest
         // query radius (10.1) plus slack for depenetration drift
         Cand<K> cd;
@@ -1157,19 +1180,26 @@ DEV void sim_tick(const Lv &lv, int r, Nj &n, EntBits eb, int hor, int jump STAM
                               (xold > n.x ? xold : n.x) + pad, (yold > n.y ? yold : n.y) + pad, cd);
         }
         STAMP(3);
-        // 4 substeps (nsim.py:263-267); collide_vs_objects has nothing physical to hit on this path.  A substep
-        // that applies no depenetration and leaves the position bit-identical has the same inputs as the next
-        // one, so the remaining substeps are no-ops and are skipped.
+        // 4 substeps (nsim.py:263-267).  Without a physically collidable entity nearby collide_vs_objects does
+        // nothing, and a substep that applies no depenetration and leaves the position bit-identical has the same
+        // inputs as the next one, so the remaining substeps are no-ops and are skipped.
+        Crush cr{0, 0, 0};
         for (int k = 0; k < 4; k++) {
             const double xb = n.x, yb = n.y;
-            bool applied = collide_vs_tiles<G, K>(lv, r, n, cd, xold, yold, fnsx, fnsy, cnsx, cnsy STAMP_PASS);
-            if (!applied && n.x == xb && n.y == yb) break;
+            if (zoo && zt.phys_near) {
+                cr.xcr = zt.xcr; cr.ycr = zt.ycr; cr.clen = zt.clen;
+                collide_vs_objects<G>(lv, z, r, n, zt, xold, yold, fnsx, fnsy, cnsx, cnsy);
+                cr.xcr = zt.xcr; cr.ycr = zt.ycr; cr.clen = zt.clen;
+            }
+            bool applied = collide_vs_tiles<G, K>(lv, r, n, cd, xold, yold, fnsx, fnsy, cnsx, cnsy, cr STAMP_PASS);
+            zt.xcr = cr.xcr; zt.ycr = cr.ycr; zt.clen = cr.clen;
+            if (!(zoo && zt.phys_near) && !applied && n.x == xb && n.y == yb) break;
         }
         STAMP(4);
-        post_collision<G, K>(lv, r, n, cd, eb, fnsx, fnsy, cnsx, cnsy);
+        post_collision<G, K, ZOO>(lv, z, r, n, cd, eb, fnsx, fnsy, cnsx, cnsy, xold, yold, zt);
         STAMP(5);
     }
-    ninja_think(n);
+    ninja_think(n, zoo ? z.blk : nullptr);
     STAMP(6);
 }
 
@@ -1332,7 +1362,7 @@ DEV void block_store_rows(const uint32_t *stage, uint32_t *dst_block, int width,
 }
 
 // G lanes per env; EPW = 64 / G envs per wavefront; blockDim.x / 64 wavefronts per workgroup
-template <int G, bool LDS_LEVEL>
+template <int G, bool LDS_LEVEL, bool ZOO>
 DEV void run(const KernelArgs &a, unsigned char *smem) {
     constexpr int EPW = WAVE / G;
     const int tid = threadIdx.x;
@@ -1378,6 +1408,32 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     lv.spawn_x = H.spawn_x; lv.spawn_y = H.spawn_y;
     lv.sw_x = H.sw_x; lv.sw_y = H.sw_y; lv.door_x = H.door_x; lv.door_y = H.door_y;
 
+    // entity zoo: this env's block and a private copy of its level's grid edges live in LDS behind the staging rows
+    Zoo z;
+    z.on = false; z.blk = nullptr; z.edges = nullptr; z.n_mov = 0; z.n_door = 0; z.n_balls = 0;
+    if constexpr (ZOO) {
+        size_t zoff = (size_t)(LDS_LEVEL ? a.lds_hot_cap : 0u) + (size_t)a.n_words_max * epb * 4 + (size_t)epb * 41 * 4;
+        zoff = (zoff + 7) & ~(size_t)7;
+        z.blk = reinterpret_cast<double *>(smem + zoff) + (size_t)eib * a.zoo_words;
+        z.edges = reinterpret_cast<uint32_t *>(smem + zoff + (size_t)epb * a.zoo_words * 8) + (size_t)eib * (2 * EDGE_WORDS_D);
+        z.on = H.has_zoo != 0;
+        z.ent_seq = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_seq);
+        z.ent_cell = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_cell);
+        z.mov_meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_mov_meta);
+        z.mov_x0 = reinterpret_cast<const double *>(a.blob + H.off_mov_x0);
+        z.mov_y0 = reinterpret_cast<const double *>(a.blob + H.off_mov_y0);
+        z.door_tab = reinterpret_cast<const uint32_t *>(a.blob + H.off_door_tab);
+        z.n_mov = (int)H.n_mov; z.n_door = (int)H.n_zdoor; z.door_words = (a.zoo_doors + 1) / 2;
+        z.n_balls = (int)H.n_balls; z.n_created = (int)H.n_created; z.db_count = H.db_count;
+        if (z.on) {
+            const int used = ZOO_HEAD + z.door_words + ZOO_MOV_WORDS * z.n_mov;
+            const double *src = a.zoo + (size_t)e * a.zoo_words;
+            for (int k = r; k < used; k += G) z.blk[k] = src[k];
+            const uint32_t *esrc = reinterpret_cast<const uint32_t *>(a.blob + H.off_edges);
+            for (int k = r; k < 2 * EDGE_WORDS_D; k += G) z.edges[k] = esrc[k];
+        }
+    }
+
 #ifdef NPP_STAMPS
     Stamps st;
     for (int i = 0; i < N_STAMP; i++) st.acc[i] = 0;
@@ -1414,7 +1470,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
                 jump = b & 1;
             }
             if (live) {
-                sim_tick<G>(lv, r, n, eb, hor, jump STAMP_PASS);
+                sim_tick<G, ZOO>(lv, z, r, n, eb, hor, jump, (int)H.n_ent STAMP_PASS);
                 executed++;
                 if (gym && (n.state == 8 || n.state == 6 || n.state == 7)) live = false;
             }
@@ -1453,6 +1509,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         if (pass == 1 && do_reset) {
             spawn_state(lv, n);
             for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
+            if (ZOO && z.on) zoo_init_block(z, r, G, false);
         }
         float *gdst = pass == 0 ? a.out.terminal_state : a.out.game_state;
         if (gdst) {
@@ -1491,6 +1548,13 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         store_state(a, env, n);
         for (int w = 0; w < nw; w++) a.ent_bits[(size_t)w * a.n + env] = eb.w[w * eb.stride];
     }
+    if constexpr (ZOO) {
+        if (valid && z.on) {
+            const int used = ZOO_HEAD + z.door_words + ZOO_MOV_WORDS * z.n_mov;
+            double *dst = a.zoo + (size_t)env * a.zoo_words;
+            for (int k = r; k < used; k += G) dst[k] = z.blk[k];
+        }
+    }
     STAMP(8);
 #ifdef NPP_STAMPS
     if (lane == 0) {
@@ -1503,10 +1567,10 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 
 // LDS_LEVEL is chosen by the host: true when every workgroup's envs play one level that fits the LDS budget
 // (the host knows the env -> level assignment), false otherwise (tables are read through L1/L2).
-template <int G, bool LDS_LEVEL>
+template <int G, bool LDS_LEVEL, bool ZOO>
 __global__ __launch_bounds__(256) void npp_step_kernel(KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    run<G, LDS_LEVEL>(a, smem);
+    run<G, LDS_LEVEL, ZOO>(a, smem);
 }
 
 // Simulator.reset / fast_reset (nsim.py:62-140) for masked envs
@@ -1522,11 +1586,23 @@ __global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
     store_state(a, env, n);
     const uint32_t *init = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
     for (uint32_t w = 0; w < H.n_words; w++) a.ent_bits[(size_t)w * a.n + env] = init[w];
+    if (a.zoo && H.has_zoo) {
+        Zoo z;
+        z.blk = a.zoo + (size_t)env * a.zoo_words;
+        z.edges = nullptr;
+        z.mov_meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_mov_meta);
+        z.mov_x0 = reinterpret_cast<const double *>(a.blob + H.off_mov_x0);
+        z.mov_y0 = reinterpret_cast<const double *>(a.blob + H.off_mov_y0);
+        z.door_tab = reinterpret_cast<const uint32_t *>(a.blob + H.off_door_tab);
+        z.n_mov = (int)H.n_mov; z.n_door = (int)H.n_zdoor; z.door_words = (a.zoo_doors + 1) / 2;
+        z.n_created = (int)H.n_created;
+        zoo_init_block(z, 0, 1, a.reset_fresh != 0);
+    }
 }
 
 // npp_restore: copy the snapshot planes of the masked envs back into the live state
 __global__ __launch_bounds__(256) void npp_restore_kernel(KernelArgs a, const double *sf, const uint32_t *su, const uint32_t *se,
-                                                          const float *sc) {
+                                                          const float *sc, const double *sz) {
     const int env = blockIdx.x * 256 + threadIdx.x;
     if (env >= a.n) return;
     if (a.reset_mask && a.reset_mask[env] == 0) return;
@@ -1535,6 +1611,8 @@ __global__ __launch_bounds__(256) void npp_restore_kernel(KernelArgs a, const do
     for (int k = 0; k < NU32; k++) a.u32[k * N + env] = su[k * N + env];
     for (int k = 0; k < a.n_words_max; k++) a.ent_bits[k * N + env] = se[k * N + env];
     for (int k = 0; k < 48; k++) a.sc_cache[(size_t)env * 48 + k] = sc[(size_t)env * 48 + k];
+    if (sz && a.zoo)
+        for (int k = 0; k < a.zoo_words; k++) a.zoo[(size_t)env * a.zoo_words + k] = sz[(size_t)env * a.zoo_words + k];
 }
 
 template <int G>
@@ -1542,9 +1620,14 @@ hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
     const int wpb = a.waves_per_block;
     const int epb = (WAVE / G) * wpb;
     const int blocks = (a.n + epb - 1) / epb;
+    if (a.zoo_active) {   // zoo levels: level tables stay in L1/L2, LDS holds the per-env zoo blocks
+        const size_t lds = lds_bytes(0, a.n_words_max, epb, a.zoo_words);
+        hipLaunchKernelGGL((npp_step_kernel<G, false, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
+        return hipGetLastError();
+    }
     const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb);
-    if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
-    else hipLaunchKernelGGL((npp_step_kernel<G, false>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
+    if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, false>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
+    else hipLaunchKernelGGL((npp_step_kernel<G, false, false>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1564,8 +1647,8 @@ hipError_t launch_step(const KernelArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint32_t *src_u32, const uint32_t *src_ent,
-                          const float *src_sc, hipStream_t s) {
-    hipLaunchKernelGGL(npp_restore_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a, src_f64, src_u32, src_ent, src_sc);
+                          const float *src_sc, const double *src_zoo, hipStream_t s) {
+    hipLaunchKernelGGL(npp_restore_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a, src_f64, src_u32, src_ent, src_sc, src_zoo);
     return hipGetLastError();
 }
 

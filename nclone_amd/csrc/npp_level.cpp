@@ -19,6 +19,12 @@ const uint16_t ORTHO_POS[34] = {0x000, 0xc30, 0x40c, 0xc20, 0x830, 0x310, 0x000,
                                 0xc30, 0x030, 0x000, 0xc00, 0xc30, 0x030, 0x000, 0x400, 0x830, 0x030, 0x400, 0xc00,
                                 0xc30, 0x830, 0x000, 0xc00, 0xc20, 0x010, 0x010, 0xc20, 0xc30, 0x030};
 
+// Grid-edge toggles of tile types 0..33 (nclone/tile_definitions.py TILE_GRID_EDGE_MAP, same 6 + 6 layout, bit k =
+// k-th entry): what drones, thwumps and shove thwumps test with is_empty_row / is_empty_column (physics.py:210-235).
+const uint16_t GRID_EDGE[34] = {0x000, 0xcf3, 0x44f, 0xf22, 0x8bc, 0x3d1, 0x6db, 0xe67, 0xdb6, 0x9f9, 0xcf3, 0xcf3,
+                                0xcf3, 0xcf3, 0x6db, 0xe67, 0xdb6, 0x9f9, 0x44f, 0x44f, 0x8bc, 0x8bc, 0xcf3, 0xcf3,
+                                0xcf3, 0xcf3, 0x3d1, 0xf22, 0xf22, 0x3d1, 0xcf3, 0xcf3, 0xcf3, 0xcf3};
+
 // Non-orthogonal piece of a tile, already in packed-segment units (12 px): 0 = none.
 // Diagonals (tile_definitions.py:189-210) and quarter circles (:214-223).
 uint16_t pack_linear(int x1, int y1, int x2, int y2) {
@@ -71,7 +77,24 @@ struct RawEnt {
     uint32_t init;
     int link_raw;  // index into raw list (door of a switch), -1 otherwise
     uint32_t type = 0;  // Entity.type (1/21 mine, 2 gold, 3 exit door, 4 exit switch, 6 locked-door switch)
+    int seq = 0;        // creation order
+    int extra = -1;     // link field for kinds without a linked entity: door table index / orientation
 };
+
+struct RawMover {
+    uint32_t kind, orientation, mode, type;
+    double x, y;
+    int seq;
+};
+
+// physics.py:317-332
+void orientation_vector(int o, double &vx, double &vy) {
+    const double diag = std::sqrt(2.0) / 2;
+    static const int sx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, sy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    o &= 7;
+    vx = (o & 1) ? sx[o] * diag : sx[o];
+    vy = (o & 1) ? sy[o] * diag : sy[o];
+}
 
 void seg_bounds_units(uint16_t s, int &x0, int &y0, int &x1, int &y1) {
     if ((s & 1u) == 0) {
@@ -174,6 +197,9 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
     L.spawn_x = map[1231] * 6;
     L.spawn_y = map[1232] * 6;
     std::vector<RawEnt> raw;
+    std::vector<RawMover> movers;
+    int next_seq = 0;       // creation order over static entities and movers alike
+    size_t seq_done = 0;    // raw entries that already have their creation number
     std::vector<std::array<double, 5>> raw_doors;
     auto cell_of = [](double px, double py) {
         int cx = clampi((int)std::fmax(std::fmin(std::floor(px / 24), 1e6), -1e6), 0, 43);
@@ -204,25 +230,53 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
             raw.push_back({EK_EXIT, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 0u, -1, 3u});
             raw.push_back({EK_SWITCH, sx, sy, cell_of(sx, sy), 1u, (int)raw.size() - 1, 4u});
             last_switch_raw = (int)raw.size() - 1;
-        } else if (type == 6) {
-            // the entity lives at its switch (entity_door_base.py:94-97); its door segment never reaches the
-            // ninja's region queries because the spatial index is snapshotted before entities load
-            if (index + 7 >= n) {
-                err = "locked door record truncated";
+        } else if (type == 5 || type == 6 || type == 8) {
+            // the entity lives at its switch (entity_door_base.py:94-97; a regular door is its own switch,
+            // entity_factory.py:198-201); its door segment never reaches the ninja's region queries because the
+            // spatial index is snapshotted before entities load.  What the door does change are the grid edges that
+            // drones and thwumps test (entity_door_base.py:62-89).
+            if (type != 5 && index + 7 >= n) {
+                err = "door record truncated";
                 return false;
             }
-            double sx = map[index + 6] * 6, sy = map[index + 7] * 6;
-            raw.push_back({EK_LOCKED, sx, sy, cell_of(sx, sy), 1u, -1, 6u});
-            {   // the door's stroke (entity_door_base.py:52-85): 24 px long, vertical for orientations 0 and 4
-                double dx = xc * 6, dy = yc * 6, orient = map[index + 3];
-                bool vertical = (orient == 0 || orient == 4);
+            double dx = xc * 6, dy = yc * 6, orient = map[index + 3];
+            double sx = type == 5 ? dx : map[index + 6] * 6, sy = type == 5 ? dy : map[index + 7] * 6;
+            bool vertical = (orient == 0 || orient == 4);
+            double vx, vy;
+            orientation_vector((int)orient, vx, vy);
+            int dcx = clampi((int)std::floor((dx - 12 * vx) / 24), 0, 43), dcy = clampi((int)std::floor((dy - 12 * vy) / 24), 0, 24);
+            int hx = 2 * (dcx + 1), hy = 2 * (dcy + 1);
+            uint32_t k0, k1;
+            if (vertical) { k0 = (uint32_t)(hx * EDGE_H + hy - 2) | 0x8000u; k1 = (uint32_t)(hx * EDGE_H + hy - 1) | 0x8000u; }
+            else { k0 = (uint32_t)((hx - 2) * EDGE_H + hy); k1 = (uint32_t)((hx - 1) * EDGE_H + hy); }
+            L.door_tab.push_back(k0 | (k1 << 16));
+            L.door_tab.push_back(type == 8 ? 0u : 1u);   // trap doors start open (entity_door_trap.py:53)
+            uint32_t kind = type == 5 ? EK_DOOR_REG : (type == 6 ? EK_LOCKED : EK_DOOR_TRAP);
+            // 2-bit state: bit 0 active, bit 1 "closed" for regular doors (locked: closed == active, trap: closed == !active)
+            raw.push_back({kind, sx, sy, cell_of(sx, sy), type == 5 ? 3u : 1u, -1, (uint32_t)type});
+            raw.back().extra = (int)(L.door_tab.size() / 2) - 1;
+            if (type == 6) {   // the door's stroke (entity_door_base.py:52-85): 24 px long, vertical for orientations 0 and 4
                 raw_doors.push_back({vertical ? dx : dx - 12, vertical ? dy - 12 : dy, vertical ? dx : dx + 12,
                                      vertical ? dy + 12 : dy, (double)(raw.size() - 1)});
             }
-        } else if (type == 5 || type == 8 || type == 10 || type == 11 || type == 14 || type == 17 || type == 20 ||
-                   type == 24 || type == 25 || type == 26 || type == 28) {
-            L.unsupported_mask |= 1u << type;
+            if (type != 6) L.has_zoo = true;
+        } else if (type == 10 || type == 11) {
+            // launch pad (entity_launch_pad.py) / one-way platform (entity_one_way_platform.py): static, oriented
+            raw.push_back({type == 10 ? EK_LAUNCH : EK_ONEWAY, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 1u, -1, (uint32_t)type});
+            raw.back().extra = ((int)map[index + 3]) & 7;
+            L.has_zoo = true;
+        } else if (type == 24) {
+            // boost pad (entity_boost_pad.py): state 1 = not touching, 3 = touching the ninja
+            raw.push_back({EK_BOOST, xc * 6, yc * 6, cell_of(xc * 6, yc * 6), 1u, -1, 24u});
+            L.has_zoo = true;
+        } else if (type == 14 || type == 17 || type == 20 || type == 25 || type == 26 || type == 28) {
+            uint32_t mk = type == 14 ? MK_DRONE : type == 17 ? MK_BOUNCE : type == 20 ? MK_THWUMP : type == 25 ? MK_BALL
+                          : type == 26 ? MK_MINI : MK_SHOVE;
+            movers.push_back({mk, ((uint32_t)(int)map[index + 3]) & 7u, ((uint32_t)(int)map[index + 4]) & 3u, (uint32_t)type,
+                              xc * 6, yc * 6, next_seq++});
+            L.has_zoo = true;
         }
+        for (; seq_done < raw.size(); seq_done++) raw[seq_done].seq = next_seq++;
         if (type == 6 || type == 8) {
             if (index + 9 < n && map[index + 7] != 0 && map[index + 8] == 0 && map[index + 9] == 0)
                 index += 10;
@@ -232,7 +286,7 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
             index += 5;
         }
     }
-    if (raw.size() > 4096) {
+    if (raw.size() + movers.size() > 4096) {
         err = "too many entities (max 4096 per level)";
         return false;
     }
@@ -248,6 +302,7 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
     for (size_t s = 0; s < order.size(); s++) slot_of[order[s]] = (int)s;
     size_t ne = raw.size();
     L.ent_x.resize(ne); L.ent_y.resize(ne); L.ent_meta.resize(ne); L.ent_map_order.resize(ne);
+    L.ent_seq.resize(ne); L.ent_cell.resize(ne);
     L.ent_start.assign(N_CELLS + 1, 0);
     L.ent_init_words.assign((ne + 15) / 16, 0);
     std::vector<int> count(N_CELLS, 0);
@@ -255,8 +310,10 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         const RawEnt &r = raw[order[s]];
         L.ent_x[s] = r.x;
         L.ent_y[s] = r.y;
-        uint32_t link = r.link_raw >= 0 ? (uint32_t)slot_of[r.link_raw] : 0xffffu;
+        uint32_t link = r.link_raw >= 0 ? (uint32_t)slot_of[r.link_raw] : (r.extra >= 0 ? (uint32_t)r.extra : 0xffffu);
         L.ent_meta[s] = r.kind | (r.init << 4) | (link << 8) | (r.type << 24);
+        L.ent_seq[s] = (uint16_t)r.seq;
+        L.ent_cell[s] = (uint16_t)r.cell;
         L.ent_init_words[s >> 4] |= r.init << ((s & 15) * 2);
         count[r.cell]++;
     }
@@ -280,6 +337,51 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
             for (int k = 0; k < 4; k++) L.door_segs.push_back(d[k]);
             L.door_segs.push_back((double)slot_of[(int)d[4]]);
         }
+    }
+    // ---- entity zoo tables
+    {
+        // movers in entity_dic order (type ascending, map order inside a type): nsim.py:235-251 walks them like that
+        std::stable_sort(movers.begin(), movers.end(), [](const RawMover &a, const RawMover &b) { return a.type < b.type; });
+        for (const RawMover &m : movers) {
+            L.mov_meta.push_back(m.kind | (m.orientation << 3) | (m.mode << 6) | ((uint32_t)m.seq << 8));
+            L.mov_x0.push_back(m.x);
+            L.mov_y0.push_back(m.y);
+            if (m.kind == MK_BALL) L.n_balls++;
+        }
+        L.n_created = next_seq;
+        L.db_count = n > 1200 ? map[1200] : 0;
+        // grid edges: nsim.py:208-215 (frame preset) + tile_segment_factory.py:283-302 (mod-2 toggles per tile)
+        std::vector<uint8_t> hor(EDGE_W * EDGE_H, 0), ver(EDGE_W * EDGE_H, 0);
+        for (int x = 0; x < EDGE_W; x++)
+            for (int y = 0; y < EDGE_H; y++) {
+                hor[x * EDGE_H + y] = (y == 0 || y == 50) ? 1 : 0;
+                ver[x * EDGE_H + y] = (x == 0 || x == 88) ? 1 : 0;
+            }
+        for (int x = 0; x < GRID_W; x++)
+            for (int y = 0; y < GRID_H; y++) {
+                int t = L.tiles[x * GRID_H + y];
+                if (t == 0 || t >= 34) continue;
+                uint16_t g = GRID_EDGE[t];
+                for (int j = 0; j < 3; j++)
+                    for (int i = 0; i < 2; i++) hor[(2 * x + i) * EDGE_H + 2 * y + j] ^= (g >> (2 * j + i)) & 1;
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 2; j++) ver[(2 * x + i) * EDGE_H + 2 * y + j] ^= (g >> (2 * i + j + 6)) & 1;
+            }
+        L.edges.assign(2 * EDGE_WORDS, 0);
+        for (int k = 0; k < EDGE_W * EDGE_H; k++) {
+            if (hor[k]) L.edges[k >> 5] |= 1u << (k & 31);
+            if (ver[k]) L.edges[EDGE_WORDS + (k >> 5)] |= 1u << (k & 31);
+        }
+        // entity_dic walk (keys ascending, creation order inside a key) for dumps / checksums
+        struct DicRef { uint32_t type; int seq; uint32_t ref; };
+        std::vector<DicRef> dic;
+        for (size_t i = 0; i < raw.size(); i++)
+            dic.push_back({raw[i].type == 4 ? 3u : raw[i].type, raw[i].seq, (uint32_t)slot_of[i]});
+        for (size_t i = 0; i < movers.size(); i++) dic.push_back({movers[i].type, movers[i].seq, 0x80000000u | (uint32_t)i});
+        std::stable_sort(dic.begin(), dic.end(), [](const DicRef &a, const DicRef &b) {
+            return a.type != b.type ? a.type < b.type : a.seq < b.seq;
+        });
+        for (const DicRef &d : dic) L.dic_order.push_back(d.ref);
     }
     if (last_switch_raw >= 0) {
         L.obs_switch = slot_of[last_switch_raw];

@@ -17,7 +17,12 @@ constexpr int GRID_H = 25;
 constexpr int N_CELLS = GRID_W * GRID_H;  // cell index = cx * 25 + cy  (x-major, like the reference's queries)
 
 // entity kinds understood by the kernels (low nibble of ent_meta)
-enum EntKind : uint32_t { EK_NONE = 0, EK_MINE = 1, EK_GOLD = 2, EK_EXIT = 3, EK_SWITCH = 4, EK_LOCKED = 6 };
+enum EntKind : uint32_t { EK_NONE = 0, EK_MINE = 1, EK_GOLD = 2, EK_EXIT = 3, EK_SWITCH = 4, EK_DOOR_REG = 5, EK_LOCKED = 6,
+                          EK_DOOR_TRAP = 7, EK_LAUNCH = 8, EK_ONEWAY = 9, EK_BOOST = 10 };
+// entities that move between grid cells ("movers"); they live in their own table, in entity_dic order
+enum MoverKind : uint32_t { MK_DRONE = 1, MK_BOUNCE = 2, MK_THWUMP = 3, MK_BALL = 4, MK_MINI = 5, MK_SHOVE = 6 };
+constexpr int EDGE_W = 89, EDGE_H = 51;                      // half-cell grid edges, key = x * 51 + y
+constexpr int EDGE_WORDS = (EDGE_W * EDGE_H + 31) / 32;      // 142 u32 per orientation
 
 // Packed collision segment (uint16), coordinates in units of 12 px relative to the owning cell's origin:
 //   linear : bit0 = 0, bits 2-3 x1, 4-5 y1, 6-7 x2, 8-9 y2
@@ -40,6 +45,18 @@ struct CompiledLevel {
     int obs_switch = -1, obs_door = -1;  // CSR slots of the exit switch / door reported in observations
     int n_thinkable = 0;               // mines
     uint32_t unsupported_mask = 0;     // bit t set if entity type t present but not simulated
+    // ---- entity zoo ----
+    std::vector<uint16_t> ent_seq;     // [n_ent] creation order (= list order inside a grid cell) of a CSR entity
+    std::vector<uint16_t> ent_cell;    // [n_ent] cell index of a CSR entity
+    std::vector<uint32_t> mov_meta;    // [n_mov] MoverKind | orientation << 3 | mode << 6 | creation order << 8
+    std::vector<double> mov_x0, mov_y0;  // [n_mov] position at creation (= spring / thwump origin)
+    std::vector<uint32_t> edges;       // hor[EDGE_WORDS] then ver[EDGE_WORDS]: tile grid edges (bit = edge present)
+    std::vector<uint32_t> door_tab;    // [n_zdoor][2]: key0 | key1 << 16 (bit 15 of a key = vertical), initial counter
+    std::vector<uint32_t> dic_order;   // entity_dic walk: CSR slot, or 0x80000000 | mover index
+    int n_created = 0;                 // entities created at load (first free list-order number)
+    int n_balls = 0;
+    double db_count = 0;               // map_data[1200]
+    bool has_zoo = false;              // any kind beyond mines / gold / exit / locked doors
 };
 
 // Returns false (and fills err) on malformed input.

@@ -142,6 +142,13 @@ class NppBatch:
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 84 * 84 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_render_player_frame(self.h, C.c_void_p(out.data_ptr())))
 
+    def entity_checksum(self, env0=0, count=None):
+        """[count, 6] f64: per-env sums over all entities in entity_dic order (see npp_entity_checksum)."""
+        count = self.n - env0 if count is None else count
+        o = np.zeros((count, 6), dtype=np.float64)
+        nat.check(self.h, self.lib.npp_entity_checksum(self.h, env0, count, o.ctypes.data_as(C.POINTER(C.c_double))))
+        return o
+
     def snapshot(self):
         """Checkpoint the state of every env on the device (one slot)."""
         nat.check(self.h, self.lib.npp_snapshot(self.h))
