@@ -148,6 +148,11 @@ int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int m
                                uint32_t *unsupported_mask);
 int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out);
 
+/* Host-only: the zoo tables the level compiler derives from map_data.  edges_out: int32[2][89*51] grid-edge counters at
+ * load (horizontal then vertical, key = x * 51 + y; tile edges of tile_segment_factory.py:283-302 plus closed doors,
+ * entity_door_base.py:78-89).  movers_out: rows of 4 doubles (Entity.type, x, y, creation order) in entity_dic order. */
+int npp_compile_level_zoo(const double *map, int64_t n, int32_t *edges_out, double *movers_out, int max_movers, int *n_movers);
+
 /* Test / debug aid for levels with moving entities: per env 6 doubles summed over the entities in the reference's
  * entity_dic order (keys ascending, creation order inside a key): sum x, sum y, sum xspeed, sum yspeed (bounce blocks and
  * death balls), sum of state codes (3*closed + 5*(state mod 7) + 11*dir + 13*touching + 17*activated), number of active

@@ -632,6 +632,35 @@ int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int m
     return NPP_OK;
 }
 
+int npp_compile_level_zoo(const double *map, int64_t n, int32_t *edges_out, double *movers_out, int max_movers, int *n_movers) {
+    if (!map || !edges_out || !n_movers) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_zoo: bad arguments");
+    CompiledLevel L;
+    std::string err;
+    if (!compile_level(map, n, L, err)) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_zoo: " + err);
+    const int NK = EDGE_W * EDGE_H;
+    for (int k = 0; k < NK; k++) {
+        edges_out[k] = (int32_t)((L.edges[k >> 5] >> (k & 31)) & 1u);
+        edges_out[NK + k] = (int32_t)((L.edges[EDGE_WORDS + (k >> 5)] >> (k & 31)) & 1u);
+    }
+    for (size_t d = 0; d + 1 < L.door_tab.size(); d += 2) {
+        uint32_t keys[2] = {L.door_tab[d] & 0xffffu, L.door_tab[d] >> 16};
+        for (uint32_t k : keys) edges_out[((k & 0x8000u) ? NK : 0) + (int)(k & 0x7fffu)] += (int32_t)L.door_tab[d + 1];
+    }
+    int nm = (int)L.mov_meta.size();
+    if (movers_out) {
+        if (nm > max_movers) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_zoo: buffer too small");
+        static const double type_of[7] = {0, 14, 17, 20, 25, 26, 28};
+        for (int m = 0; m < nm; m++) {
+            movers_out[4 * m] = type_of[L.mov_meta[m] & 7u];
+            movers_out[4 * m + 1] = L.mov_x0[m];
+            movers_out[4 * m + 2] = L.mov_y0[m];
+            movers_out[4 * m + 3] = (double)(L.mov_meta[m] >> 8);
+        }
+    }
+    *n_movers = nm;
+    return NPP_OK;
+}
+
 int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out) {
     if (!map || !out || !n_out) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_entities: bad arguments");
     CompiledLevel L;

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <type_traits>
+
 #include "npp_internal.hpp"
 #include "npp_level.hpp"
 
@@ -651,9 +653,14 @@ DEV double rcp_inrange(double b) {
 // fallback.  CLOSEST(m) fills `m` with the lane's best candidate; everything else is identical.
 struct DepenIO {
     double x, y, vx, vy, fnsx, fnsy, cnsx, cnsy;
-    double xcr, ycr, clen;   // crush accumulators (ninja.py:344-346); dead code unless a thwump can crush (zoo levels)
     int fcount, ccount, applied;
 };
+// zoo kernels also carry the crush accumulators (ninja.py:344-346); only a thwump can make them matter
+struct DepenIOZ : DepenIO {
+    double xcr, ycr, clen;
+};
+DEV void crush_add(DepenIO &, double, double, double) {}
+DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += dx; io.ycr += dy; io.clen += len; }
 
 #define NPP_DEPEN_STEP(io, m, BREAK)                                                                   \
     {                                                                                                  \
@@ -677,7 +684,7 @@ struct DepenIO {
         const double depen_x = norm_dx * depen_len, depen_y = norm_dy * depen_len;                     \
         (io).x += depen_x;                                                                             \
         (io).y += depen_y;                                                                             \
-        (io).xcr += depen_x; (io).ycr += depen_y; (io).clen += depen_len;                              \
+        crush_add((io), depen_x, depen_y, depen_len);                                                  \
         double dot_product = (io).vx * ddx + (io).vy * ddy;                                            \
         if (dot_product < 0) {                                                                         \
             double cross_product = (io).vx * ddy - (io).vy * ddx;                                      \
@@ -690,8 +697,8 @@ struct DepenIO {
     }
 
 // LDS-table fallback of the whole loop (rare: the query left the gathered region)
-template <int G>
-__device__ __noinline__ DepenIO depen_generic(TileRefs lv, int r, double gx0, double gy0, double gx1, double gy1, DepenIO io) {
+template <int G, typename IO>
+__device__ __noinline__ IO depen_generic(TileRefs lv, int r, double gx0, double gy0, double gx1, double gy1, IO io) {
     const int c0x = cell_coord(gx0, 43), c1x = cell_coord(gx1, 43), c0y = cell_coord(gy0, 24), c1y = cell_coord(gy1, 24);
     for (int it = 0; it < 32; it++) {
         Best m;
@@ -723,7 +730,11 @@ __device__ __noinline__ DepenIO depen_generic(TileRefs lv, int r, double gx0, do
 
 // Ninja.collide_vs_tiles (ninja.py:269-379).  Returns true when at least one depenetration was applied.
 struct Crush { double xcr, ycr, clen; };
-template <int G, int K>
+DEV void crush_in(DepenIO &, const Crush &) {}
+DEV void crush_in(DepenIOZ &io, const Crush &c) { io.xcr = c.xcr; io.ycr = c.ycr; io.clen = c.clen; }
+DEV void crush_out(const DepenIO &, Crush &) {}
+DEV void crush_out(const DepenIOZ &io, Crush &c) { c.xcr = io.xcr; c.ycr = io.ycr; c.clen = io.clen; }
+template <int G, int K, bool ZOO>
 DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double xold, double yold, double &fnsx, double &fnsy,
                           double &cnsx, double &cnsy, Crush &cr STAMP_ARG) {
     double dx = n.x - xold, dy = n.y - yold;
@@ -767,11 +778,12 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
         for (int k = 0; k < K; k++) gp |= cand_in_box(cd, k, qg) ? (1u << k) : 0u;
         if (!group_any<G>(gp != 0)) return false;   // empty list: result == 0 at the first iteration
     }
-    DepenIO io;
+    using IO = typename std::conditional<ZOO, DepenIOZ, DepenIO>::type;
+    IO io;
     io.x = n.x; io.y = n.y; io.vx = n.vx; io.vy = n.vy;
     io.fnsx = fnsx; io.fnsy = fnsy; io.cnsx = cnsx; io.cnsy = cnsy;
     io.fcount = n.fcount; io.ccount = n.ccount; io.applied = 0;
-    io.xcr = cr.xcr; io.ycr = cr.ycr; io.clen = cr.clen;
+    crush_in(io, cr);
     STAMP(9);   // sweep + gather setup
     if (fast) {
         for (int it = 0; it < 32; it++) {
@@ -804,12 +816,12 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
 #ifdef NPP_STAMPS
         st.acc[11] += 1;   // substeps that took the LDS fallback
 #endif
-        io = depen_generic<G>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, gx0, gy0, gx1, gy1, io);
+        io = depen_generic<G, IO>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, gx0, gy0, gx1, gy1, io);
     }
     n.x = io.x; n.y = io.y; n.vx = io.vx; n.vy = io.vy;
     fnsx = io.fnsx; fnsy = io.fnsy; cnsx = io.cnsx; cnsy = io.cnsy;
     n.fcount = io.fcount; n.ccount = io.ccount;
-    cr.xcr = io.xcr; cr.ycr = io.ycr; cr.clen = io.clen;
+    crush_out(io, cr);
     return io.applied != 0;
 }
 
@@ -1191,7 +1203,7 @@ DEV void sim_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb, int hor,
                 collide_vs_objects<G>(lv, z, r, n, zt, xold, yold, fnsx, fnsy, cnsx, cnsy);
                 cr.xcr = zt.xcr; cr.ycr = zt.ycr; cr.clen = zt.clen;
             }
-            bool applied = collide_vs_tiles<G, K>(lv, r, n, cd, xold, yold, fnsx, fnsy, cnsx, cnsy, cr STAMP_PASS);
+            bool applied = collide_vs_tiles<G, K, ZOO>(lv, r, n, cd, xold, yold, fnsx, fnsy, cnsx, cnsy, cr STAMP_PASS);
             zt.xcr = cr.xcr; zt.ycr = cr.ycr; zt.clen = cr.clen;
             if (!(zoo && zt.phys_near) && !applied && n.x == xb && n.y == yb) break;
         }

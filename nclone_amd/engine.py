@@ -208,3 +208,15 @@ def compile_level_entities(map_data):
     nat.check(None, L.npp_compile_level_entities(
         m.ctypes.data_as(C.POINTER(C.c_double)), len(m), buf.ctypes.data_as(C.POINTER(C.c_double)), len(buf), C.byref(n)))
     return buf[: n.value].copy()
+
+
+def compile_level_zoo(map_data):
+    """Host-only: (hor [89, 51], ver [89, 51] grid-edge counters at load, movers [n, 4] = type, x, y, creation order)."""
+    lib = nat.lib()
+    m = np.ascontiguousarray(np.asarray(map_data, dtype=np.float64))
+    edges = np.zeros(2 * 89 * 51, dtype=np.int32)
+    mov = np.zeros((1024, 4), dtype=np.float64)
+    n = C.c_int(0)
+    nat.check(None, lib.npp_compile_level_zoo(m.ctypes.data_as(C.POINTER(C.c_double)), len(m), edges.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              mov.ctypes.data_as(C.POINTER(C.c_double)), len(mov), C.byref(n)))
+    return edges[: 89 * 51].reshape(89, 51), edges[89 * 51 :].reshape(89, 51), mov[: n.value].copy()

@@ -2130,6 +2130,13 @@ int osim_dump_entities(const OSim *S, double *out, int max_rows)
     return r;
 }
 
+/* live grid edges (tiles + doors), x-major [89][51]; nonzero = blocked */
+void osim_dump_edges(const OSim *S, int *hor, int *ver)
+{
+    for (int x = 0; x < 89; x++)
+        for (int y = 0; y < 51; y++) { hor[x * 51 + y] = S->hor_edge[x][y]; ver[x * 51 + y] = S->ver_edge[x][y]; }
+}
+
 int osim_entity_states(const OSim *S, int *out, int max)
 {
     int r = 0;

@@ -62,6 +62,7 @@ def _lib(variant):
     lib.osim_dump_entities.restype = C.c_int
     lib.osim_entity_states.argtypes = [P, C.POINTER(C.c_int), C.c_int]
     lib.osim_entity_states.restype = C.c_int
+    lib.osim_dump_edges.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.osim_entity_checksum.argtypes = [P, C.POINTER(C.c_double)]
     lib.osim_env_step.argtypes = [P, C.c_int, C.c_int, C.POINTER(C.c_int)]
     lib.osim_env_step.restype = C.c_int
@@ -138,6 +139,13 @@ class Oracle:
         n = self.lib.osim_dump_entities(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), len(buf))
         assert n >= 0
         return buf[:n].copy()
+
+    def edges(self):
+        """(hor, ver) int arrays [89, 51]: the grid-edge counters drones and thwumps test."""
+        hor = np.zeros(89 * 51, dtype=np.int32)
+        ver = np.zeros(89 * 51, dtype=np.int32)
+        self.lib.osim_dump_edges(self.h, hor.ctypes.data_as(C.POINTER(C.c_int)), ver.ctypes.data_as(C.POINTER(C.c_int)))
+        return hor.reshape(89, 51), ver.reshape(89, 51)
 
     def entity_checksum(self):
         o = np.zeros(6, dtype=np.float64)

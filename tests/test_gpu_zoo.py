@@ -1,0 +1,187 @@
+"""GPU parity for the entity zoo: regular / trap doors, launch pads, one-way platforms, zap and
+mini drones, bounce blocks, thwumps, boost pads, death balls, shove thwumps.
+
+Fixtures: tests/golden/zoo.npz (make_golden_zoo.py, produced by running the reference): the 26 bc_replays whose maps
+hold those entities and 9 random-action rollouts on such maps, with a per-tick checksum over every entity.
+The HIP path is compared BIT-FOR-BIT with the oracle's multiply-square twin (ninja state, discrete state, entity
+checksum) and with the reference fixtures under the north-star bars (f32 positions within 1e-5, discrete state
+identical); libm's pow is not correctly rounded, so death-ball speeds of the twin can differ from the reference in the
+last bit (measured: <= 2e-15 on these fixtures, ninja trajectories identical).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+POS_TOL = 1e-5
+GS_TOL = 2e-6
+ENT_TOL = 1e-9
+
+
+def _batch(n, **kw):
+    from nclone_amd.engine import NppBatch
+
+    return NppBatch(n, **kw)
+
+
+def _disc(i):
+    return i[:, :20].clip(0, 255).astype(np.uint8)
+
+
+def _run_replays(golden, oracle_mod, idx, geometry=None, copies=1):
+    c, z = golden.z("corpus"), golden.z("zoo")
+    n = len(idx) * copies
+    b = _batch(n, autoreset=False)
+    b.load_levels([c["m%d" % i] for i in idx])
+    if geometry:
+        b.set_launch_geometry(*geometry)
+    b.assign_levels(np.arange(n) % len(idx))          # first creation: replay semantics (no reset after the load)
+    sims = []
+    for i in idx:
+        o = oracle_mod.Oracle("mul")
+        o.load(c["m%d" % i].astype(np.float64))
+        sims.append(o)
+    T = [len(z["t%d" % i]) for i in idx]
+    tmax = max(T)
+    inputs = np.zeros((tmax, n), dtype=np.uint8)
+    for e in range(n):
+        k = e % len(idx)
+        inputs[: T[k], e] = c["in%d" % idx[k]][: T[k]]
+    d_in = torch.from_numpy(inputs).cuda()
+    final = c["final"]
+    ticks = 0
+    for tick in range(tmax):
+        b.tick(d_in[tick : tick + 1])
+        f, di = b.dump_state()
+        cs = b.entity_checksum()
+        for k, i in enumerate(idx):
+            if tick >= T[k]:
+                continue
+            h, j = oracle_mod.controls(int(inputs[tick, k]))
+            sims[k].tick(h, j)
+            of, od = sims[k].core()
+            oc = sims[k].entity_checksum()
+            for e in range(k, n, len(idx)):
+                assert np.array_equal(f[e], of), (i, tick, e, f[e], of)
+                assert np.array_equal(di[e, :22], od[:22]), (i, tick, e)
+                assert np.array_equal(cs[e], oc), (i, tick, e, cs[e] - oc)
+            # reference fixtures
+            ref = z["t%d" % i][tick]
+            d32 = np.abs(f[k, :4].astype(np.float32).astype(np.float64) - ref.astype(np.float32).astype(np.float64)).max()
+            assert d32 <= POS_TOL, (i, tick, d32)
+            assert np.array_equal(_disc(di[k : k + 1])[0], z["d%d" % i][tick]), (i, tick)
+            assert np.abs(cs[k] - z["e%d" % i][tick]).max() <= ENT_TOL, (i, tick)
+            if tick == T[k] - 1:
+                assert int(final[i, 0]) == T[k] and di[k, 0] == int(final[i, 1])
+                assert np.array_equal(f[k, :2], final[i, 2:4])
+            ticks += 1
+    return ticks, b.launch_geometry()
+
+
+def test_zoo_replays_bit_exact(golden, oracle_mod):
+    """All 26 zoo bc_replays, one env each, every tick: with the 104 others of test_gpu_parity.py that is 130 of 130."""
+    z = golden.z("zoo")
+    ticks, geo = _run_replays(golden, oracle_mod, [int(i) for i in z["idx"]])
+    print("zoo replay ticks %d, geometry %s" % (ticks, geo))
+    assert ticks == 5886
+
+
+@pytest.mark.parametrize("geometry", [(1, 1), (4, 2), (64, 1)])
+def test_zoo_lane_group_geometries(golden, oracle_mod, geometry):
+    """Lane ownership of movers, ballots for list-order numbers and the merged neighbourhood walk must not depend on G.
+    (The host may raise G when the zoo blocks of 64/G envs per wavefront do not fit the LDS budget.)"""
+    z = golden.z("zoo")
+    idx = [int(i) for i in z["idx"]][:6]
+    ticks, geo = _run_replays(golden, oracle_mod, idx, geometry=geometry, copies=3)
+    print("requested", geometry, "ran", geo)
+
+
+def test_zoo_rollouts_step_api(golden):
+    """npp_step with in-kernel auto-reset on 9 zoo maps against reference rollouts (hp.reset() on termination).  The
+    first episode runs with the first creation of the entities (ball-ball repulsion on), later ones do not."""
+    z = golden.z("zoo")
+    n = int(z["n_rollouts"][0])
+    b = _batch(n, autoreset=True)
+    b.load_levels([z["rm%d" % r] for r in range(n)])
+    b.assign_levels(np.arange(n))
+    steps = len(z["ra0"])
+    acts = np.stack([z["ra%d" % r] for r in range(n)], axis=1)
+    d_acts = torch.from_numpy(acts).cuda()
+    rows = np.zeros(n, dtype=np.int64)
+    episodes = 0
+    for s in range(steps):
+        b.step(d_acts[s], frame_skip=4)
+        b.sync()
+        flags = b.flags.cpu().numpy()
+        frames = b.frames.cpu().numpy().astype(np.int64)
+        gs = b.game_state.cpu().numpy()
+        term_gs = b.terminal_state.cpu().numpy()
+        mask = b.action_mask.cpu().numpy()
+        f, di = b.dump_state()
+        cs = b.entity_checksum()
+        for r in range(n):
+            ex, term, frame = z["rs%d" % r][s]
+            assert frames[r] == ex, (r, s, frames[r], ex)
+            kind = 1 if flags[r] & 1 else (2 if flags[r] & 2 else 0)
+            assert kind == term, (r, s, flags[r], term)
+            rows[r] += ex
+            got = term_gs[r] if term else gs[r]
+            assert np.abs(got[:40] - z["rg%d" % r][s]).max() <= GS_TOL, (r, s)
+            if not term:
+                assert list(mask[r]) == [(int(z["rk%d" % r][s]) >> k) & 1 for k in range(6)], (r, s)
+                ref = z["rt%d" % r][rows[r] - 1]
+                assert np.abs(f[r, :4] - ref).max() <= POS_TOL, (r, s, f[r, :4], ref)
+                assert np.array_equal(_disc(di[r : r + 1])[0], z["rd%d" % r][rows[r] - 1]), (r, s)
+                assert np.abs(cs[r] - z["re%d" % r][rows[r] - 1]).max() <= ENT_TOL, (r, s, cs[r] - z["re%d" % r][rows[r] - 1])
+            else:
+                episodes += 1
+                assert di[r, 22] == 0 and di[r, 0] == 0
+    assert episodes >= 10
+    print("zoo rollout steps %d x %d envs, episodes %d" % (steps, n, episodes))
+
+
+def test_zoo_mixed_with_plain_levels_and_checkpoint(golden, oracle_mod):
+    """Zoo and plain levels in one batch (interleaved inside wavefronts), snapshot / restore of the zoo blocks, and the
+    oracle twin as referee at the end."""
+    c, z, r = golden.z("corpus"), golden.z("zoo"), golden.z("rollouts")
+    zi = [int(i) for i in z["idx"]][:5]
+    levels = [c["m%d" % i].astype(np.float64) for i in zi] + [r["m%d" % k] for k in range(3)]
+    n = 96
+    b = _batch(n, autoreset=False)
+    b.load_levels(levels)
+    lvl = np.arange(n) % len(levels)
+    b.assign_levels(lvl)
+    rng = np.random.default_rng(17)
+    acts = rng.integers(0, 6, size=(60, n)).astype(np.uint8)
+    d = torch.from_numpy(acts).cuda()
+    for s in range(30):
+        b.step(d[s])
+    b.snapshot()
+    f0, i0 = b.dump_state()
+    c0 = b.entity_checksum()
+    for s in range(30, 60):
+        b.step(d[s])
+    f1, i1 = b.dump_state()
+    c1 = b.entity_checksum()
+    b.restore()
+    fr, ir = b.dump_state()
+    assert np.array_equal(fr, f0) and np.array_equal(ir, i0) and np.array_equal(b.entity_checksum(), c0)
+    for s in range(30, 60):
+        b.step(d[s])
+    f2, i2 = b.dump_state()
+    assert np.array_equal(f2, f1) and np.array_equal(i2, i1) and np.array_equal(b.entity_checksum(), c1)
+    # referee: the oracle twin stepping the same actions (terminal envs are not stepped again without auto-reset)
+    for e in range(0, n, 7):
+        o = oracle_mod.Oracle("mul")
+        o.load(levels[lvl[e]])
+        done = False
+        for s in range(60):
+            if not done:
+                _, fl = o.env_step(int(acts[s, e]), 4)
+                done = fl != 0
+        of, od = o.core()
+        assert np.array_equal(f1[e], of), (e, lvl[e])
+        assert np.array_equal(i1[e, :22], od[:22]), (e, lvl[e])
+        assert np.array_equal(c1[e], o.entity_checksum()), (e, lvl[e])

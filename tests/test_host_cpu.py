@@ -41,8 +41,7 @@ def test_level_compiler_matches_reference_tables(native, golden):
         m = c["m%d" % i].astype(np.float64)
         rows, uns = compile_level_segments(m)
         assert np.array_equal(rows, csr[bytes(c["csr%d" % i]).decode()]), i
-        types = set(int(x) for x in sigs[i].split(",") if x)
-        assert (uns != 0) == (not types <= {1, 2, 3, 6, 21})
+        assert uns == 0          # every entity type of the reference's factory is simulated
         if "ent%d" % i in c.files:
             ref = sorted((kind[int(t)], x, y, cx, cy) for _, t, x, y, cx, cy, _, _ in c["ent%d" % i])
             got = sorted((int(k), x, y, cx, cy) for k, x, y, cx, cy, _ in compile_level_entities(m))
@@ -53,6 +52,27 @@ def test_level_compiler_matches_reference_tables(native, golden):
         ref = sorted((kind[int(t)], x, y, cx, cy) for _, t, x, y, cx, cy, _, _ in lg["ent%d" % k])
         got = sorted((int(kk), x, y, cx, cy) for kk, x, y, cx, cy, _ in compile_level_entities(lg["L%d" % k]))
         assert ref == got, k
+
+
+def test_level_compiler_zoo_tables_match_oracle(native, golden, oracle_mod):
+    """Grid edges (what drones / thwumps test) and the mover table of the 26 zoo maps against the oracle's own build of
+    them (the oracle is pinned by the reference's replays, where a wrong edge sends a drone the wrong way)."""
+    from nclone_amd.engine import compile_level_zoo
+
+    c, z = golden.z("corpus"), golden.z("zoo")
+    for i in z["idx"]:
+        m = c["m%d" % i].astype(np.float64)
+        hor, ver, mov = compile_level_zoo(m)
+        o = oracle_mod.Oracle("pow")
+        o.load(m)
+        ohor, over = o.edges()
+        assert np.array_equal(hor, ohor) and np.array_equal(ver, over), i
+        # movers: entity_dic order = type ascending, creation order inside a type
+        key = mov[:, 0] * 1e6 + mov[:, 3]
+        assert np.all(np.diff(key) > 0), i
+        raw = m.astype(int)
+        want = sum(int(t in (14, 17, 20, 25, 26, 28)) for t in raw[1230::5][: (len(raw) - 1230) // 5]) if 6 not in raw[1230::5] and 8 not in raw[1230::5] else len(mov)
+        assert len(mov) == want, i
 
 
 def test_level_compiler_edge_cases(native):
