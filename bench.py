@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--gather-obs", action="store_true", help="RCCL all_gather of game_state each step (config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c0", choices=["c0", "mines", "doors", "zoo"],
+                    help="c0 = config 2 (the headline metric); the others are secondary level sets")
     args = ap.parse_args()
 
     import torch
@@ -115,9 +117,10 @@ def main():
         torch.cuda.set_device(local_rank)
 
     from nclone_amd.engine import NppBatch
-    from nclone_amd.levels import curriculum0_levels
+    from nclone_amd import levels as level_sets
 
-    levels, tags = curriculum0_levels()
+    levels, tags = {"c0": level_sets.curriculum0_levels, "mines": level_sets.mine_levels, "doors": level_sets.door_levels,
+                    "zoo": level_sets.zoo_levels}[args.workload]()
     n = args.envs_per_gpu
     K, W = args.steps, args.warmup
     b = NppBatch(n, device=local_rank, autoreset=True)
@@ -177,10 +180,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "config 2: %d envs/GPU, curriculum_level=0 (exit+switch only: 78 bc_replays maps + "
-                            "maze:tiny/hills:simple seeds 100001-100025 = %d levels x 64 envs), game_state+"
-                            "action_mask+entity_positions obs, frame_skip 4, uniform random actions, auto-reset"
-                            % (n, len(levels)),
+                "workload": ("config 2: %d envs/GPU, curriculum_level=0 (exit+switch only: 78 bc_replays maps + "
+                             "maze:tiny/hills:simple seeds 100001-100025 = %d levels x 64 envs), game_state+"
+                             "action_mask+entity_positions obs, frame_skip 4, uniform random actions, auto-reset"
+                             % (n, len(levels))) if args.workload == "c0" else
+                            ("secondary level set '%s': %d envs/GPU on %d levels x 64 envs, same observation and action "
+                             "distribution as config 2" % (args.workload, n, len(levels))),
                 "envs_per_gpu": n,
                 "frame_skip": FRAME_SKIP,
                 "ticks_per_s": value * FRAME_SKIP,

@@ -65,3 +65,15 @@ def door_levels():
             out.append(g["L%d" % k])
             tags.append(n)
     return out, tags
+
+
+def zoo_levels():
+    """The 26 bc_replays maps with the entity zoo (doors, launch / boost pads, one-ways, drones, bounce blocks, thwumps,
+    death balls, shove thwumps): SURVEY.md 8(f) row 2."""
+    c = np.load(os.path.join(_GOLDEN, "corpus.npz"))
+    z = np.load(os.path.join(_GOLDEN, "zoo.npz"))
+    out, tags = [], []
+    for i in z["idx"]:
+        out.append(c["m%d" % i].astype(np.float64))
+        tags.append("replay:%d" % i)
+    return out, tags

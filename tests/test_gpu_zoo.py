@@ -185,3 +185,44 @@ def test_zoo_mixed_with_plain_levels_and_checkpoint(golden, oracle_mod):
         assert np.array_equal(f1[e], of), (e, lvl[e])
         assert np.array_equal(i1[e, :22], od[:22]), (e, lvl[e])
         assert np.array_equal(c1[e], o.entity_checksum()), (e, lvl[e])
+
+
+def test_zoo_full_size_sample_vs_oracle(oracle_mod):
+    """8192 envs on the 26 zoo maps (64 consecutive envs per map), 40 random-action steps with auto-reset; a sample of envs
+    is replayed on the oracle twin and must match bit for bit (ninja state and entity checksum); determinism across a
+    second run of the same inputs."""
+    from nclone_amd.levels import zoo_levels
+
+    levels, _ = zoo_levels()
+    n = 8192
+    lvl = (np.arange(n) // 64) % len(levels)
+    rng = np.random.default_rng(99)
+    acts = rng.integers(0, 6, size=(40, n)).astype(np.uint8)
+    d = torch.from_numpy(acts).cuda()
+    runs = []
+    for rep in range(2):
+        b = _batch(n, autoreset=True)
+        b.load_levels(levels)
+        b.assign_levels(lvl)
+        resets = np.zeros(n, dtype=np.int64)
+        for s in range(40):
+            b.step(d[s])
+            resets += (b.flags.cpu().numpy() & 11) != 0
+        f, i = b.dump_state()
+        runs.append((f, i, b.entity_checksum(), resets))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    f, i, cs, resets = runs[0]
+    checked = 0
+    for e in list(range(0, n, 97)) + list(np.nonzero(resets)[0][:20]):
+        o = oracle_mod.Oracle("mul")
+        o.load(levels[lvl[e]])
+        for s in range(40):
+            _, fl = o.env_step(int(acts[s, e]), 4)
+            if fl or o.frame >= 10000:
+                o.reset()
+        of, od = o.core()
+        assert np.array_equal(f[e], of), (e, lvl[e])
+        assert np.array_equal(i[e, :22], od[:22]), (e, lvl[e])
+        assert np.array_equal(cs[e], o.entity_checksum()), (e, lvl[e])
+        checked += 1
+    print("zoo full size: %d envs, %d checked against the oracle, %d episodes ended" % (n, checked, int(resets.sum())))
