@@ -423,12 +423,23 @@ DEV bool ball_think(const Lv &lv, const Zoo &z, int r, const Nj &n, int m, int b
     }
     const double xold = x, yold = y;
     const TileRefs tr{lv.seg_start, lv.segs, lv.bounds};
-    const double time = sweep_generic<G>(tr, r, xold, yold, vx, vy, 8 * 0.5);
+    // cells that the sweep (radius 4 + 1) and the first closest-point query (radius 8) can look at: when they hold no
+    // segment at all, the sweep returns 1 and the query returns "nothing" (physics.py:116-128, 141-180)
+    bool open_space;
+    {
+        const double xn = xold + vx, yn = yold + vy;
+        const int c0x = cell_coord((xold < xn ? xold : xn) - 8, 43), c1x = cell_coord((xold > xn ? xold : xn) + 8, 43);
+        const int c0y = cell_coord((yold < yn ? yold : yn) - 8, 24), c1y = cell_coord((yold > yn ? yold : yn) + 8, 24);
+        int nseg = 0;
+        for (int xc = c0x; xc <= c1x; xc++) nseg += (int)lv.seg_start[xc * 25 + c1y + 1] - (int)lv.seg_start[xc * 25 + c0y];
+        open_space = nseg == 0;
+    }
+    const double time = open_space ? 1.0 : sweep_generic<G>(tr, r, xold, yold, vx, vy, 8 * 0.5);
     x = xold + time * vx;
     y = yold + time * vy;
     double xnormal = 0, ynormal = 0;
     bool bail = false;
-    for (int it = 0; it < 16; it++) {
+    for (int it = 0; it < (open_space ? 0 : 16); it++) {
         const Best c = closest_generic<G>(tr, r, x, y, 8.0);
         if (c.idx == 0x7fffffff) break;
         const int result = (c.idx & 1) ? -1 : 1;
@@ -592,33 +603,30 @@ DEV void collide_vs_objects(const Lv &lv, const Zoo &z, int r, Nj &n, ZTick &zt,
                             double &fnsy, double &cnsx, double &cnsy) {
     const int cx = zt.gcx, cy = zt.gcy;
     const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < 43 ? cx + 1 : 43, y0 = cy > 0 ? cy - 1 : 0, y1 = cy < 24 ? cy + 1 : 24;
-    int last = -1;
+    // the next mover in list order is looked up once and again only after it has been consumed
+    int nk = 0;
+    int nm = zoo_next<G>(z, r, -1, 0x7fffffff, x0, x1, y0, y1, true, nk);
     for (int xc = x0; xc <= x1; xc++) {
         const int i0 = lv.ent_start[xc * 25 + y0], i1 = lv.ent_start[xc * 25 + y1 + 1];
         for (int i = i0; i < i1; i++) {
             const uint32_t meta = lv.ent_meta[i];
             if ((meta & 15u) != EK_ONEWAY) continue;
             const int key = zoo_key(z.ent_cell[i], z.ent_seq[i]);
-            for (;;) {
-                int mk;
-                const int m = zoo_next<G>(z, r, last, key, x0, x1, y0, y1, true, mk);
-                if (m < 0) break;
-                mover_physical(z, m, n, zt, fnsx, fnsy, cnsx, cnsy);
-                last = mk;
+            while (nm >= 0 && nk < key) {
+                mover_physical(z, nm, n, zt, fnsx, fnsy, cnsx, cnsy);
+                const int last = nk;
+                nm = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, true, nk);
             }
             double nx, ny, len;
             orientation_vec((meta >> 8) & 7u, nx, ny);
             if (oneway_depen(lv.ent_x[i], lv.ent_y[i], nx, ny, n, xold, yold, len))
                 apply_physical(n, zt, 11, nx, ny, len, fnsx, fnsy, cnsx, cnsy);
-            last = key;
         }
     }
-    for (;;) {
-        int mk;
-        const int m = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, true, mk);
-        if (m < 0) break;
-        mover_physical(z, m, n, zt, fnsx, fnsy, cnsx, cnsy);
-        last = mk;
+    while (nm >= 0) {
+        mover_physical(z, nm, n, zt, fnsx, fnsy, cnsx, cnsy);
+        const int last = nk;
+        nm = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, true, nk);
     }
 }
 
@@ -688,7 +696,8 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
     const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < 43 ? cx + 1 : 43, y0 = cy > 0 ? cy - 1 : 0, y1 = cy < 24 ? cy + 1 : 24;
     int pend0 = -1, pend1 = -1;
     double wall_normal = 0;
-    int last = -1;
+    int nk = 0;
+    int nm = z.n_mov ? zoo_next<G>(z, r, -1, 0x7fffffff, x0, x1, y0, y1, false, nk) : -1;
     for (int xc = x0; xc <= x1; xc++) {
         const int i0 = lv.ent_start[xc * 25 + y0], i1 = lv.ent_start[xc * 25 + y1 + 1];
         for (int i = i0; i < i1; i++) {
@@ -696,17 +705,14 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
             const uint32_t kind = meta & 15u;
             const uint32_t st = ent_get(eb, i);
             if (kind == EK_EXIT && st == 0) continue;   // not in the grid: it does not even take a place in the order
-            const int key = zoo_key(z.ent_cell[i], z.ent_seq[i]);
-            if (z.n_mov) {
-                for (;;) {
-                    int mk;
-                    const int m = zoo_next<G>(z, r, last, key, x0, x1, y0, y1, false, mk);
-                    if (m < 0) break;
-                    mover_logical(z, m, n, wall_normal);
-                    last = mk;
+            if (nm >= 0) {
+                const int key = zoo_key(z.ent_cell[i], z.ent_seq[i]);
+                while (nm >= 0 && nk < key) {
+                    mover_logical(z, nm, n, wall_normal);
+                    const int last = nk;
+                    nm = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, false, nk);
                 }
             }
-            last = key;
             const double ex = lv.ent_x[i], ey = lv.ent_y[i];
             if (kind == EK_MINE) {   // entity_toggle_mine.py:120-128
                 if (valid_target(n.state) && st == 0 && overlaps(ex, ey, 4.0 + NINJA_RADIUS, n.x, n.y)) {
@@ -772,14 +778,10 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
             }
         }
     }
-    if (z.n_mov) {
-        for (;;) {
-            int mk;
-            const int m = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, false, mk);
-            if (m < 0) break;
-            mover_logical(z, m, n, wall_normal);
-            last = mk;
-        }
+    while (nm >= 0) {
+        mover_logical(z, nm, n, wall_normal);
+        const int last = nk;
+        nm = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, false, nk);
     }
     if (pend0 >= 0) ent_set(eb, pend0, 1);
     if (pend1 >= 0) ent_set(eb, pend1, 1);

@@ -25,12 +25,14 @@ def main():
                           [os.path.join(csrc, f) for f in ("npp_kernels.hip", "npp_render.hip", "npp_capi.cpp", "npp_level.cpp")])
     nat.LIB_PATH = out
     from nclone_amd.engine import NppBatch
-    from nclone_amd.levels import curriculum0_levels
+    from nclone_amd import levels as level_sets
 
     lib = nat.lib()
     lib.npp_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int, C.c_int]
     n = 8192
-    levels, _ = curriculum0_levels()
+    workload = os.environ.get("NPP_STAMP_WORKLOAD", "c0")
+    levels, _ = {"c0": level_sets.curriculum0_levels, "zoo": level_sets.zoo_levels, "mines": level_sets.mine_levels}[workload]()
+    print("workload", workload, len(levels), "levels")
     rng = np.random.default_rng(0)
     K, W = 100, 100
     acts = torch.from_numpy(rng.integers(0, 6, size=(K + W, n)).astype(np.uint8)).cuda()
