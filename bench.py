@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--gather-obs", action="store_true", help="RCCL all_gather of game_state each step (config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--async-streams", type=int, default=4,
+                    help="also time the same K steps with the envs split into this many independent sub-batches on "
+                         "separate HIP streams (reported as async_subbatches, never as value); 0 = skip")
     ap.add_argument("--workload", default="c0", choices=["c0", "mines", "doors", "zoo"],
                     help="c0 = config 2 (the headline metric); the others are secondary level sets")
     args = ap.parse_args()
@@ -162,6 +165,50 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # secondary figure: the same envs as S independent sub-batches, each stepped K times on its own HIP stream with no
+    # cross-stream synchronisation until the end (an asynchronous / double-buffered vector env).  A synchronous step lasts
+    # as long as its slowest env's serial fp64 chain; independent sub-batches let other envs' work fill that tail.
+    async_rep = None
+    S = args.async_streams
+    if S > 1 and n % (S * 64) == 0 and not args.gather_obs:
+        sub = n // S
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        subs = []
+        for k in range(S):
+            with torch.cuda.stream(streams[k]):
+                sb = NppBatch(sub, device=local_rank, autoreset=True, stream=streams[k])
+                sb.load_levels(levels)
+                sb.assign_levels(((np.arange(sub) + k * sub) // 64) % len(levels))
+                subs.append(sb)
+        torch.cuda.synchronize()
+        views = [acts[:, k * sub:(k + 1) * sub].contiguous() for k in range(S)]
+
+        def run_async(k0, k1):
+            for t in range(k0, k1):
+                for k in range(S):
+                    subs[k].step(views[k][t], FRAME_SKIP, want_terminal=False)
+
+        run_async(0, W)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        run_async(W, W + K)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        adt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([adt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            adt = float(tt.item())
+        async_rep = {"streams": S, "envs_per_stream": sub, "value": world * n * K / adt, "unit": "env-steps/s",
+                     "ms_per_step_all_streams": adt * 1e3 / K,
+                     "note": "same envs, levels and actions as `value`, stepped as independent sub-batches on separate HIP "
+                             "streams (no barrier between sub-batches); not the headline metric"}
+        for sb in subs:
+            sb.close()
+
     if rank == 0:
         value = world * n * K / dt
         launch_us = dev_ms * 1e3 / K   # HIP events on the launch stream: average duration per npp_step launch
@@ -207,6 +254,8 @@ def main():
                         "the HBM fraction is tiny by construction (SURVEY.md 8(d))",
             },
         }
+        if async_rep is not None:
+            line["async_subbatches"] = async_rep
         if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(levels)

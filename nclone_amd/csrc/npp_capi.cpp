@@ -489,6 +489,14 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     return NPP_OK;
 }
 
+int npp_render_global_view(npp_handle h, uint8_t *d_out) {
+    if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_global_view: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_global_view: no levels loaded");
+    KernelArgs a = base_args(h);
+    HIP_TRY(h, launch_global_view(a, d_out, h->stream));
+    return NPP_OK;
+}
+
 int npp_dump_state(npp_handle h, int env0, int count, double *f64_out, int32_t *i32_out) {
     if (!h || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_dump_state: bad range");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_dump_state: no levels loaded");

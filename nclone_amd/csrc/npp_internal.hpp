@@ -127,5 +127,6 @@ hipError_t launch_reset(const KernelArgs &a, hipStream_t s);
 hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint32_t *src_u32, const uint32_t *src_ent,
                           const float *src_sc, const double *src_zoo, hipStream_t s);
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
+hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
 
 }  // namespace npp

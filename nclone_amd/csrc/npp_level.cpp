@@ -255,10 +255,9 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
             // 2-bit state: bit 0 active, bit 1 "closed" for regular doors (locked: closed == active, trap: closed == !active)
             raw.push_back({kind, sx, sy, cell_of(sx, sy), type == 5 ? 3u : 1u, -1, (uint32_t)type});
             raw.back().extra = (int)(L.door_tab.size() / 2) - 1;
-            if (type == 6) {   // the door's stroke (entity_door_base.py:52-85): 24 px long, vertical for orientations 0 and 4
-                raw_doors.push_back({vertical ? dx : dx - 12, vertical ? dy - 12 : dy, vertical ? dx : dx + 12,
-                                     vertical ? dy + 12 : dy, (double)(raw.size() - 1)});
-            }
+            // the door's stroke (entity_door_base.py:52-85): 24 px long, vertical for orientations 0 and 4
+            raw_doors.push_back({vertical ? dx : dx - 12, vertical ? dy - 12 : dy, vertical ? dx : dx + 12,
+                                 vertical ? dy + 12 : dy, (double)(raw.size() - 1)});
             if (type != 6) L.has_zoo = true;
         } else if (type == 10 || type == 11) {
             // launch pad (entity_launch_pad.py) / one-way platform (entity_one_way_platform.py): static, oriented
@@ -324,15 +323,23 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         acc += count[c];
     }
     L.ent_start[N_CELLS] = (uint16_t)acc;
-    // draw order of the reference's entity layer: groups by Entity.type in order of first appearance while walking
-    // entity_dic keys 1..28 (door 3 before its switch 4), map order inside a group
+    // movers in entity_dic order (type ascending, map order inside a type): nsim.py:235-251 walks them like that
+    std::stable_sort(movers.begin(), movers.end(), [](const RawMover &a, const RawMover &b) { return a.type < b.type; });
+    // draw order of the reference's entity layer
     {
-        std::vector<int> ord(raw.size());
-        for (size_t i = 0; i < raw.size(); i++) ord[i] = (int)i;
-        auto rank = [](uint32_t t) { return t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 2 : t == 4 ? 3 : t == 6 ? 4 : 5; };
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return rank(raw[a].type) < rank(raw[b].type); });
-        L.raster_order.resize(raw.size());
-        for (size_t i = 0; i < ord.size(); i++) L.raster_order[i] = (uint16_t)slot_of[ord[i]];
+        // entity_renderer.py:100-150: groups by Entity.type in order of first appearance while walking entity_dic
+        // (keys ascending; under key 3 the door precedes its switch, type 4), creation order inside a group; movers are
+        // referenced as 0x8000 | index
+        struct DrawRef { double key; int seq; uint16_t ref; };
+        std::vector<DrawRef> dr;
+        for (size_t i = 0; i < raw.size(); i++)
+            dr.push_back({raw[i].type == 4 ? 3.5 : (double)raw[i].type, raw[i].seq, (uint16_t)slot_of[i]});
+        for (size_t i = 0; i < movers.size(); i++) dr.push_back({(double)movers[i].type, movers[i].seq, (uint16_t)(0x8000u | i)});
+        std::stable_sort(dr.begin(), dr.end(), [](const DrawRef &a, const DrawRef &b) {
+            return a.key != b.key ? a.key < b.key : a.seq < b.seq;
+        });
+        L.raster_order.clear();
+        for (const DrawRef &d : dr) L.raster_order.push_back(d.ref);
         for (auto &d : raw_doors) {
             for (int k = 0; k < 4; k++) L.door_segs.push_back(d[k]);
             L.door_segs.push_back((double)slot_of[(int)d[4]]);
@@ -340,8 +347,6 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
     }
     // ---- entity zoo tables
     {
-        // movers in entity_dic order (type ascending, map order inside a type): nsim.py:235-251 walks them like that
-        std::stable_sort(movers.begin(), movers.end(), [](const RawMover &a, const RawMover &b) { return a.type < b.type; });
         for (const RawMover &m : movers) {
             L.mov_meta.push_back(m.kind | (m.orientation << 3) | (m.mode << 6) | ((uint32_t)m.seq << 8));
             L.mov_x0.push_back(m.x);

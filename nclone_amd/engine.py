@@ -31,7 +31,7 @@ class NppBatch:
     Counterpart of N instances of the reference's NPlayHeadless (nclone/nplay_headless.py:28).
     """
 
-    def __init__(self, n_envs, device=0, autoreset=True, allow_unsupported=False, frame_centered=False):
+    def __init__(self, n_envs, device=0, autoreset=True, allow_unsupported=False, frame_centered=False, stream=None):
         self.lib = nat.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("nclone_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -44,7 +44,8 @@ class NppBatch:
         self.h = h
         self.n_levels = 0
         with torch.cuda.device(self.device):
-            self.stream = torch.cuda.current_stream()
+            # every launch of this handle is ordered on ONE HIP stream; handles on different streams overlap on the GPU
+            self.stream = stream if stream is not None else torch.cuda.current_stream()
             nat.check(self.h, self.lib.npp_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
             N = self.n
             self.game_state = torch.zeros((N, 41), dtype=torch.float32, device=self.device)
@@ -141,6 +142,11 @@ class NppBatch:
         """out: uint8 CUDA tensor [N, 84, 84] (or [N, 84, 84, 1]) filled with the player_frame of every env."""
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 84 * 84 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_render_player_frame(self.h, C.c_void_p(out.data_ptr())))
+
+    def render_global_view(self, out):
+        """out: uint8 CUDA tensor [N, 176, 100] (or [N, 176, 100, 1]): the reference's global_view of every env."""
+        assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 176 * 100 and out.is_contiguous()
+        nat.check(self.h, self.lib.npp_render_global_view(self.h, C.c_void_p(out.data_ptr())))
 
     def entity_checksum(self, env0=0, count=None):
         """[count, 6] f64: per-env sums over all entities in entity_dic order (see npp_entity_checksum)."""

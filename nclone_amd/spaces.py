@@ -62,4 +62,5 @@ def observation_space(visual=False, spatial_context=False):
         spaces["spatial_context"] = Box(-1.0, 1.0, (112,), np.float32)
     if visual:
         spaces["player_frame"] = Box(0, 255, (84, 84, 1), np.uint8)
+        spaces["global_view"] = Box(0, 255, (176, 100, 1), np.uint8)   # RENDERED_VIEW_HEIGHT x WIDTH (constants.py:18-19)
     return Dict(spaces)

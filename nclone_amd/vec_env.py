@@ -60,6 +60,7 @@ class NppVecEnvironment:
         self._frame = None
         if self.enable_visual_observations:
             self._frame = torch.zeros((self.num_envs, 84, 84, 1), dtype=torch.uint8, device=self._b.device)
+            self._global = torch.zeros((self.num_envs, 176, 100, 1), dtype=torch.uint8, device=self._b.device)
 
     # -- helpers ------------------------------------------------------------------------------------------------
     def _conv(self, t):
@@ -77,6 +78,8 @@ class NppVecEnvironment:
         if self._frame is not None:
             b.render_player_frame(self._frame)
             obs["player_frame"] = self._conv(self._frame)
+            b.render_global_view(self._global)
+            obs["global_view"] = self._conv(self._global)
         return obs
 
     # -- Gymnasium surface ----------------------------------------------------------------------------------------

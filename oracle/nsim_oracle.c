@@ -153,6 +153,7 @@ typedef struct Entity {
     double xdir, ydir;        /* shove thwump */
     int activated;
     int touching;             /* boost pad */
+    double door_x, door_y;    /* the door's own position (the entity itself sits at its switch) */
     int is_vertical, edge[2][2], open_timer;   /* doors: grid edges they own (entity_door_base.py:69-89) */
     int index;                /* Entity.index (entities.py: per-type creation counter) */
 } Entity;
@@ -404,6 +405,8 @@ static void door_init(Entity *e, int orientation, double sw_xc, double sw_yc)
     double vx, vy;
     orientation_vector(orientation, &vx, &vy);
     e->orientation = orientation;
+    e->door_x = e->x;
+    e->door_y = e->y;
     e->is_vertical = (orientation == 0 || orientation == 4);
     int dcx = iclamp((int)floor((e->x - 12 * vx) / 24), 0, 43);
     int dcy = iclamp((int)floor((e->y - 12 * vy) / 24), 0, 24);
@@ -2126,6 +2129,48 @@ int osim_dump_entities(const OSim *S, double *out, int max_rows)
         double *o = out + 8 * r++;
         o[0] = e->dic_key; o[1] = e->type; o[2] = e->x; o[3] = e->y; o[4] = e->cx; o[5] = e->cy;
         o[6] = e->kind == K_MINE ? e->state : -1; o[7] = e->active;
+    }
+    return r;
+}
+
+/* what the reference's entity layer would draw (entity_renderer.py:57-150), one row of 13 doubles per entity in entity_dic
+ * order: type, x, y, active, state (mines) / switch_hit (exit door), closed (doors), normal x, normal y (oriented kinds),
+ * door stroke x1, y1, x2, y2 (0 when the entity has no door segment), draw shape (0 disc of `radius`, 1 oriented stroke,
+ * 2 square) with the radius / semi side in the last column packed as shape * 1000 + size */
+int osim_dump_draw(const OSim *S, double *out, int max)
+{
+    int r = 0;
+    for (int i = 0; i < S->ndic && r < max; i++) {
+        const Entity *e = S->dic_order[i];
+        double *o = out + 13 * r++;
+        memset(o, 0, sizeof(double) * 13);
+        o[0] = e->type; o[1] = e->x; o[2] = e->y; o[3] = e->active;
+        o[4] = e->kind == K_EXIT ? e->switch_hit : e->state;
+        double size = 0;
+        int shape = 0;
+        switch (e->kind) {
+        case K_MINE: size = e->radius; break;
+        case K_GOLD: size = 6; break;
+        case K_EXIT: size = 12; break;
+        case K_SWITCH: size = 6; break;
+        case K_LOCKED: case K_DOOR_TRAP: size = 5; break;
+        case K_DOOR_REG: size = 10; break;
+        case K_LAUNCH: size = 6; shape = 1; break;
+        case K_ONEWAY: size = 12; shape = 1; break;
+        case K_DRONE: size = e->drone_radius; break;
+        case K_BOUNCE: case K_THWUMP: size = 9; shape = 2; break;
+        case K_BOOST: size = 6; break;
+        case K_BALL: size = 5; break;
+        case K_SHOVE: size = 8; break;   /* hasattr(entity, "RADIUS") wins over SEMI_SIDE (entity_renderer.py:178-185) */
+        }
+        o[12] = shape * 1000 + size;
+        if (e->kind == K_LAUNCH || e->kind == K_ONEWAY) { o[6] = e->nx; o[7] = e->ny; }
+        if (e->kind == K_LOCKED || e->kind == K_DOOR_REG || e->kind == K_DOOR_TRAP) {
+            o[5] = e->closed;
+            /* entity_door_base.py:70-85 */
+            if (e->is_vertical) { o[8] = e->door_x; o[9] = e->door_y - 12; o[10] = e->door_x; o[11] = e->door_y + 12; }
+            else { o[8] = e->door_x - 12; o[9] = e->door_y; o[10] = e->door_x + 12; o[11] = e->door_y; }
+        }
     }
     return r;
 }

@@ -62,6 +62,8 @@ def _lib(variant):
     lib.osim_dump_entities.restype = C.c_int
     lib.osim_entity_states.argtypes = [P, C.POINTER(C.c_int), C.c_int]
     lib.osim_entity_states.restype = C.c_int
+    lib.osim_dump_draw.argtypes = [P, C.POINTER(C.c_double), C.c_int]
+    lib.osim_dump_draw.restype = C.c_int
     lib.osim_dump_edges.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.osim_entity_checksum.argtypes = [P, C.POINTER(C.c_double)]
     lib.osim_env_step.argtypes = [P, C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -88,6 +90,7 @@ class Oracle:
 
     def load(self, map_data):
         m = np.ascontiguousarray(np.asarray(map_data, dtype=np.float64))
+        self._map = m
         r = self.lib.osim_load(self.h, m.ctypes.data_as(C.POINTER(C.c_double)), len(m))
         if r < 0:
             raise ValueError("map_data too short")
@@ -139,6 +142,21 @@ class Oracle:
         n = self.lib.osim_dump_entities(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), len(buf))
         assert n >= 0
         return buf[:n].copy()
+
+    def draw_list(self):
+        """[n, 13] rows of what the entity layer would draw, entity_dic order (see osim_dump_draw)."""
+        buf = np.zeros((4096, 13), dtype=np.float64)
+        n = self.lib.osim_dump_draw(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), len(buf))
+        return buf[:n].copy()
+
+    def tiles(self):
+        """[44, 25] tile ids incl. the border (map_loader.py:22-37)."""
+        t = np.ones((44, 25), dtype=np.int64)
+        m = np.asarray(self._map)
+        for x in range(42):
+            for y in range(23):
+                t[x + 1, y + 1] = int(m[184 + x + 42 * y])
+        return t
 
     def edges(self):
         """(hor, ver) int arrays [89, 51]: the grid-edge counters drones and thwumps test."""

@@ -53,6 +53,81 @@ def test_player_frame_centered(golden):
     _check(golden, centered=True)
 
 
+def _zoo_batch_and_oracles(golden, oracle_mod, centered, n_steps=60):
+    """A few zoo + plain levels stepped with random actions on the GPU and on the oracle twin (same bits), so that the
+    oracle can tell the numpy rasteriser where every entity is."""
+    from nclone_amd.engine import NppBatch
+
+    c, z, r = golden.z("corpus"), golden.z("zoo"), golden.z("rollouts")
+    idx = [int(i) for i in z["idx"]]
+    levels = [c["m%d" % i].astype(np.float64) for i in (idx[0], idx[3], idx[12], idx[20])] + [r["m3"], r["m24"]]
+    n = len(levels) * 2
+    lvl = np.arange(n) % len(levels)
+    b = NppBatch(n, autoreset=False, frame_centered=centered)
+    b.load_levels(levels)
+    b.assign_levels(lvl)
+    rng = np.random.default_rng(31)
+    acts = rng.integers(0, 6, size=(n_steps, n)).astype(np.uint8)
+    d = torch.from_numpy(acts).cuda()
+    for s in range(n_steps):
+        b.step(d[s])
+    sims = []
+    for e in range(n):
+        o = oracle_mod.Oracle("mul")
+        o.load(levels[lvl[e]])
+        done = False
+        for s in range(n_steps):
+            if not done:
+                _, fl = o.env_step(int(acts[s, e]), 4)
+                done = fl != 0
+        sims.append(o)
+    f, _ = b.dump_state()
+    for e in range(n):
+        assert np.array_equal(f[e], sims[e].core()[0])
+    return b, sims, f
+
+
+@pytest.mark.parametrize("centered", [False, True])
+def test_player_frame_with_zoo_entities(golden, oracle_mod, centered):
+    """Doors, launch pads / one-ways (oriented strokes), drones, bounce blocks and thwumps (squares), boost pads, death balls
+    in the player frame; entity positions come from the oracle twin.  Same tolerance as the plain frames."""
+    from tests.raster_ref import player_frame_rows
+
+    b, sims, f = _zoo_batch_and_oracles(golden, oracle_mod, centered)
+    out = torch.zeros((b.n, 84, 84), dtype=torch.uint8, device="cuda")
+    b.render_player_frame(out)
+    frames = out.cpu().numpy()
+    drawn = 0
+    for e in range(b.n):
+        ref, edge = player_frame_rows(sims[e].tiles(), sims[e].draw_list(), f[e, 0], f[e, 1], centered=centered)
+        got = frames[e].astype(np.int64)
+        dlt = np.abs(got - ref.astype(np.int64))
+        bad = np.argwhere((dlt > 0) & ~edge)
+        assert len(bad) == 0, (e, f[e, :2], [(tuple(p), int(got[tuple(p)]), int(ref[tuple(p)])) for p in bad[:8]])
+        assert dlt.max(initial=0) <= 64 and dlt.mean() < 2.0
+        drawn += int(ref.any())
+    assert drawn >= b.n // 2
+
+
+def test_global_view(golden, oracle_mod):
+    """global_view = the reference's cv2.resize(frame, (100, 176), INTER_AREA) of the whole canvas (swapped constants
+    included), against the numpy restatement: destination pixels whose source rectangle touches no primitive edge are
+    exact, the others within the edge tolerance scaled by the edge fraction."""
+    from tests.raster_ref import global_view
+
+    b, sims, f = _zoo_batch_and_oracles(golden, oracle_mod, False, n_steps=30)
+    out = torch.zeros((b.n, 176, 100), dtype=torch.uint8, device="cuda")
+    b.render_global_view(out)
+    views = out.cpu().numpy()
+    for e in range(0, b.n, 2)[:6]:
+        ref, ef = global_view(sims[e].tiles(), sims[e].draw_list(), f[e, 0], f[e, 1])
+        dlt = np.abs(views[e].astype(np.int64) - ref.astype(np.int64))
+        assert np.all(dlt[ef == 0] <= 1), (e, np.argwhere((dlt > 1) & (ef == 0))[:5])    # float rounding of the mean only
+        assert np.all(dlt <= 2 + 64 * ef), (e, dlt.max())
+        assert dlt.mean() < 1.0
+        assert ref.std() > 10       # a real picture, not a constant
+
+
 def test_vec_env_surface(golden):
     """Gymnasium-shaped classes: keys, shapes, dtypes, unbatched adapter, facade replay to a win."""
     from nclone_amd.replay import CompactReplay, validate_replays
