@@ -125,6 +125,11 @@ int npp_observe(npp_handle h, const npp_step_out *out);
 /* player_frame (84x84 u8) around each ninja, rasterised on device (nsim_renderer.py:71-134 +
  * observation_processor.py:207-282 crop incl. its axis swap).  d_out is [N,84,84]. */
 int npp_render_player_frame(npp_handle h, uint8_t *d_out);
+/* switch_states observation (gym_environment/npp_environment.py:1782-1847): f32[n_envs][25] = up to 5 locked doors x
+ * [switch x / 1056, switch y / 600, door x / 1056, door y / 600, collected]; the reference's door position falls back to the
+ * switch position (its segment has no `p1`), reproduced.  No runnable reference for this one: parity by source reading. */
+int npp_switch_states(npp_handle h, float *d_out);
+
 /* global_view (observation_processor.py:304-328): the (600 x 1056) gray frame through cv2.resize(frame, (100, 176), INTER_AREA).
  * The reference's RENDERED_VIEW_WIDTH / HEIGHT are swapped (gym_environment/constants.py:18-19), so the frame is squashed to
  * 176 rows x 100 columns; reproduced as is (area-weighted mean of the source pixels).  d_out: u8[n_envs][176][100]. */

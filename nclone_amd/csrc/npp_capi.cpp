@@ -359,6 +359,7 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.n_created = (uint32_t)L.n_created;
         H.n_balls = (uint32_t)L.n_balls;
         H.db_count = L.db_count;
+        for (int k = 0; k < 5; k++) H.locked_slots[k] = L.locked_slots[k];
         if (L.has_zoo) {
             any_zoo = true;
             zoo_doors = std::max(zoo_doors, (int)H.n_zdoor);
@@ -486,6 +487,14 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_player_frame: no levels loaded");
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_render(a, d_out, (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0, h->stream));
+    return NPP_OK;
+}
+
+int npp_switch_states(npp_handle h, float *d_out) {
+    if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_switch_states: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_switch_states: no levels loaded");
+    KernelArgs a = base_args(h);
+    HIP_TRY(h, launch_switch_states(a, d_out, h->stream));
     return NPP_OK;
 }
 

@@ -46,6 +46,8 @@ struct LevelHdr {
     uint32_t n_created;
     uint32_t n_balls;
     double db_count;
+    int32_t locked_slots[5];   // CSR slots of the first five locked doors (entity_dic[6] order), -1 = none
+    int32_t pad_;
     double spawn_x, spawn_y;
     double sw_x, sw_y, door_x, door_y;
 };
@@ -128,5 +130,6 @@ hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint
                           const float *src_sc, const double *src_zoo, hipStream_t s);
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
 hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
+hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
 
 }  // namespace npp

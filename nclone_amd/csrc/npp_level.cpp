@@ -388,6 +388,11 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         });
         for (const DicRef &d : dic) L.dic_order.push_back(d.ref);
     }
+    {
+        int k = 0;
+        for (size_t i = 0; i < raw.size() && k < 5; i++)
+            if (raw[i].kind == EK_LOCKED) L.locked_slots[k++] = slot_of[i];
+    }
     if (last_switch_raw >= 0) {
         L.obs_switch = slot_of[last_switch_raw];
         L.obs_door = slot_of[raw[last_switch_raw].link_raw];

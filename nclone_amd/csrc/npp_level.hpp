@@ -53,6 +53,7 @@ struct CompiledLevel {
     std::vector<uint32_t> edges;       // hor[EDGE_WORDS] then ver[EDGE_WORDS]: tile grid edges (bit = edge present)
     std::vector<uint32_t> door_tab;    // [n_zdoor][2]: key0 | key1 << 16 (bit 15 of a key = vertical), initial counter
     std::vector<uint32_t> dic_order;   // entity_dic walk: CSR slot, or 0x80000000 | mover index
+    int locked_slots[5] = {-1, -1, -1, -1, -1};   // CSR slots of the first five locked doors in creation order
     int n_created = 0;                 // entities created at load (first free list-order number)
     int n_balls = 0;
     double db_count = 0;               // map_data[1200]

@@ -347,7 +347,36 @@ __global__ __launch_bounds__(128) void npp_global_view_kernel(KernelArgs a, uint
     out[((size_t)env * GV_ROWS + r) * GV_COLS + c] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
 }
 
+// switch_states (gym_environment/npp_environment.py:1782-1847): up to MAX_LOCKED_DOORS = 5 locked doors x [switch x, switch y,
+// door x, door y, collected].  _extract_locked_door_positions looks for `segment.p1`, which GridSegmentLinear does not have
+// (entities.py: x1, y1, x2, y2), so the "door" position falls back to the entity's xpos / ypos -- the switch position
+// (entity_door_base.py:94-97).  Reproduced as is.
+__global__ __launch_bounds__(256) void npp_switch_states_kernel(KernelArgs a, float *out) {
+    const int env = blockIdx.x * 256 + threadIdx.x;
+    if (env >= a.n) return;
+    const LevelHdr &H = a.hdr[a.env_level[env]];
+    const double *ex = reinterpret_cast<const double *>(a.blob + H.off_ent_x);
+    const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);
+    float *o = out + (size_t)env * 25;
+    for (int k = 0; k < 5; k++) {
+        const int slot = H.locked_slots[k];
+        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (slot >= 0) {
+            const double sx = ex[slot] / 1056.0, sy = ey[slot] / 600.0;
+            const float fx = (float)(sx < 0.0 ? 0.0 : (sx > 1.0 ? 1.0 : sx)), fy = (float)(sy < 0.0 ? 0.0 : (sy > 1.0 ? 1.0 : sy));
+            const uint32_t st = (a.ent_bits[(size_t)(slot >> 4) * a.n + env] >> ((slot & 15) * 2)) & 3u;
+            v[0] = fx; v[1] = fy; v[2] = fx; v[3] = fy; v[4] = (st & 1u) ? 0.f : 1.f;
+        }
+        for (int j = 0; j < 5; j++) o[5 * k + j] = v[j];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(npp_switch_states_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a, d_out);
+    return hipGetLastError();
+}
 
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s) {
     hipLaunchKernelGGL(npp_render_kernel, dim3(a.n), dim3(256), 0, s, a, d_out, centered);

@@ -143,6 +143,14 @@ class NppBatch:
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 84 * 84 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_render_player_frame(self.h, C.c_void_p(out.data_ptr())))
 
+    def switch_states(self, out=None):
+        """float32 CUDA tensor [N, 25]: the reference's switch_states observation (5 locked doors x 5 features)."""
+        if out is None:
+            out = torch.zeros((self.n, 25), dtype=torch.float32, device=self.device)
+        assert out.dtype == torch.float32 and out.is_cuda and out.numel() == self.n * 25 and out.is_contiguous()
+        nat.check(self.h, self.lib.npp_switch_states(self.h, C.c_void_p(out.data_ptr())))
+        return out
+
     def render_global_view(self, out):
         """out: uint8 CUDA tensor [N, 176, 100] (or [N, 176, 100, 1]): the reference's global_view of every env."""
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 176 * 100 and out.is_contiguous()

@@ -52,7 +52,7 @@ def action_space():
     return Discrete(6)
 
 
-def observation_space(visual=False, spatial_context=False):
+def observation_space(visual=False, spatial_context=False, switch_states=False):
     spaces = {
         "game_state": Box(-1.0, 1.0, (41,), np.float32),
         "action_mask": Box(0, 1, (6,), np.int8),
@@ -60,6 +60,8 @@ def observation_space(visual=False, spatial_context=False):
     }
     if spatial_context:
         spaces["spatial_context"] = Box(-1.0, 1.0, (112,), np.float32)
+    if switch_states:
+        spaces["switch_states"] = Box(0.0, 1.0, (25,), np.float32)
     if visual:
         spaces["player_frame"] = Box(0, 255, (84, 84, 1), np.uint8)
         spaces["global_view"] = Box(0, 255, (176, 100, 1), np.uint8)   # RENDERED_VIEW_HEIGHT x WIDTH (constants.py:18-19)

@@ -38,7 +38,8 @@ class NppVecEnvironment:
     metadata = {"render_modes": []}
 
     def __init__(self, levels, num_envs, level_ids=None, frame_skip=4, device=0, enable_visual_observations=False,
-                 truncation_limit=10000, output="torch", autoreset=True, enable_spatial_context=False):
+                 truncation_limit=10000, output="torch", autoreset=True, enable_spatial_context=False,
+                 enable_switch_states=False):
         assert output in ("torch", "numpy")
         self.num_envs = int(num_envs)
         self.frame_skip = int(frame_skip)
@@ -56,6 +57,8 @@ class NppVecEnvironment:
         self._b.set_truncation_limit(truncation_limit)
         if enable_spatial_context:
             self._b.enable_spatial_context()
+        self._switch_states = (torch.zeros((self.num_envs, 25), dtype=torch.float32, device=self._b.device)
+                               if enable_switch_states else None)
         self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
         self._frame = None
         if self.enable_visual_observations:
@@ -75,6 +78,8 @@ class NppVecEnvironment:
         }
         if b.spatial_context is not None:
             obs["spatial_context"] = self._conv(b.spatial_context)
+        if self._switch_states is not None:
+            obs["switch_states"] = self._conv(b.switch_states(self._switch_states))
         if self._frame is not None:
             b.render_player_frame(self._frame)
             obs["player_frame"] = self._conv(self._frame)
@@ -254,6 +259,33 @@ class NPlayHeadless:
         self._b.observe()
         p = self._b.entity_pos[0].cpu().numpy().astype(np.float64)
         return float(p[4] * 1056.0), float(p[5] * 600.0)
+
+    def _entities(self):
+        """(compiled rows [kind, x, y, cx, cy, init], live 2-bit states) of the loaded level, map order."""
+        from .engine import compile_level_entities
+
+        return compile_level_entities(self.current_map_data), self._b.dump_entities(0)
+
+    def locked_doors(self):
+        """Locked-door entities (entity_dic[6]) as simple records: the entity sits at its switch (xpos, ypos == sw_xpos,
+        sw_ypos), `active` until the switch is collected, `closed` likewise (nplay_headless.py:714-716)."""
+        from types import SimpleNamespace
+
+        rows, st = self._entities()
+        return [SimpleNamespace(type=6, xpos=float(r[1]), ypos=float(r[2]), sw_xpos=float(r[1]), sw_ypos=float(r[2]),
+                                active=bool(st[i] & 1), closed=bool(st[i] & 1))
+                for i, r in enumerate(rows) if int(r[0]) == 6]
+
+    def get_mine_entities(self):
+        """(toggle mines of type 1, of type 21) with xpos, ypos, state (0 toggled / deadly, 1 untoggled, 2 toggling)."""
+        from types import SimpleNamespace
+
+        rows, st = self._entities()
+        m1, m21 = [], []
+        for i, r in enumerate(rows):
+            if int(r[0]) == 1:
+                (m1 if int(r[5]) == 0 else m21).append(SimpleNamespace(xpos=float(r[1]), ypos=float(r[2]), state=int(st[i]), active=True))
+        return m1, m21
 
     def exit(self):
         if self._b is not None:

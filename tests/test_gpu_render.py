@@ -171,3 +171,48 @@ def test_vec_env_surface(golden):
     for k, i in enumerate(idx):
         assert res[k]["ticks"] == int(final[i, 0]) and res[k]["won"] == (int(final[i, 1]) == 8)
         assert (res[k]["x"], res[k]["y"]) == (final[i, 2], final[i, 3])
+
+
+def test_switch_states_and_facade_entity_views(golden):
+    """switch_states (25 f32: 5 locked doors x [switch xy, "door" xy = switch xy as in the reference, collected]) on the
+    locked-door levels, cross-checked with the entity dump; NPlayHeadless.locked_doors / get_mine_entities.
+    The reference cannot run this code here (gymnasium), so the layout follows npp_environment.py:1782-1847 by reading."""
+    from nclone_amd.engine import NppBatch, compile_level_entities
+    from nclone_amd.levels import door_levels
+    from nclone_amd.vec_env import NPlayHeadless, NppVecEnvironment
+
+    levels, _ = door_levels()
+    n = 4 * len(levels)
+    b = NppBatch(n, autoreset=False)
+    b.load_levels(levels)
+    lvl = np.arange(n) % len(levels)
+    b.assign_levels(lvl)
+    rng = np.random.default_rng(4)
+    acts = torch.from_numpy(rng.integers(0, 6, size=(200, n)).astype(np.uint8)).cuda()
+    opened = 0
+    for s in range(200):
+        b.step(acts[s])
+    ss = b.switch_states().cpu().numpy()
+    for e in range(n):
+        rows = compile_level_entities(levels[lvl[e]])
+        st = b.dump_entities(e)
+        doors = [(r, st[i]) for i, r in enumerate(rows) if int(r[0]) == 6][:5]
+        want = np.zeros(25, dtype=np.float32)
+        for k, (r, s_) in enumerate(doors):
+            x = np.float32(np.clip(r[1] / 1056.0, 0.0, 1.0))
+            y = np.float32(np.clip(r[2] / 600.0, 0.0, 1.0))
+            want[5 * k : 5 * k + 5] = [x, y, x, y, 0.0 if (s_ & 1) else 1.0]
+            opened += int(not (s_ & 1))
+        assert np.array_equal(ss[e], want), (e, ss[e], want)
+    assert len(levels) > 0
+    v = NppVecEnvironment(levels[:2], 8, enable_switch_states=True)
+    obs, _ = v.reset()
+    assert obs["switch_states"].shape == (8, 25) and obs["switch_states"].dtype == torch.float32
+    v.close()
+    hp = NPlayHeadless()
+    hp.load_map_from_map_data(levels[0])
+    d = hp.locked_doors()
+    assert len(d) >= 1 and all(x.active and x.closed for x in d)
+    m1, m21 = hp.get_mine_entities()
+    assert all(m.state == 0 for m in m1) and all(m.state == 1 for m in m21)
+    hp.exit()
