@@ -140,6 +140,7 @@ def test_vec_env_surface(golden):
     assert obs["game_state"].shape == (130, 41) and obs["game_state"].dtype == np.float32
     assert obs["action_mask"].shape == (130, 6) and obs["action_mask"].dtype == np.int8
     assert obs["entity_positions"].shape == (130, 6) and obs["player_frame"].shape == (130, 84, 84, 1)
+    assert obs["global_view"].shape == (130, 176, 100, 1) and obs["global_view"].dtype == np.uint8
     obs, rew, term, trunc, info = v.step(np.full(130, 2, dtype=np.uint8))
     assert rew.shape == (130,) and term.dtype == np.bool_ and trunc.shape == (130,)
     assert (info["frames_executed"] == 4).all()

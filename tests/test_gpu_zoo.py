@@ -226,3 +226,22 @@ def test_zoo_full_size_sample_vs_oracle(oracle_mod):
         assert np.array_equal(cs[e], o.entity_checksum()), (e, lvl[e])
         checked += 1
     print("zoo full size: %d envs, %d checked against the oracle, %d episodes ended" % (n, checked, int(resets.sum())))
+
+
+def test_all_130_replays_validate_in_one_batch(golden):
+    """tools/test_replay_playback.py for the whole bc_replays corpus at once (one env per replay, plain and zoo levels
+    mixed in the same wavefronts): tick count, win / death and final position of every replay as the reference recorded
+    them (corpus.npz `final`); 128 of 130 win."""
+    from nclone_amd.replay import CompactReplay, validate_replays
+
+    c = golden.z("corpus")
+    final = c["final"]
+    reps = [CompactReplay(bytes(c["m%d" % i]), list(c["in%d" % i])) for i in range(len(final))]
+    res = validate_replays(reps)
+    wins = 0
+    for i, r in enumerate(res):
+        assert r["ticks"] == int(final[i, 0]), (i, r, final[i])
+        assert r["won"] == (int(final[i, 1]) == 8) and r["died"] == (int(final[i, 1]) in (6, 7)), (i, r, final[i])
+        assert (r["x"], r["y"]) == (final[i, 2], final[i, 3]), (i, r, final[i])
+        wins += r["won"]
+    assert len(res) == 130 and wins == int(np.sum(final[:, 1] == 8)) == 128
