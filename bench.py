@@ -170,7 +170,7 @@ def main():
     # as long as its slowest env's serial fp64 chain; independent sub-batches let other envs' work fill that tail.
     async_rep = None
     S = args.async_streams
-    if S > 1 and n % (S * 64) == 0 and not args.gather_obs:
+    if S > 1 and world == 1 and n % (S * 64) == 0 and not args.gather_obs:   # single-GPU runs only: a secondary figure
         sub = n // S
         streams = [torch.cuda.Stream() for _ in range(S)]
         subs = []
