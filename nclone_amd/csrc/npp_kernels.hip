@@ -1325,8 +1325,9 @@ DEV void write_spatial_context(const KernelArgs &a, const LevelHdr &H, Nj &n, En
     const double *ex = reinterpret_cast<const double *>(a.blob + H.off_ent_x);
     const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);
     const uint32_t *meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_ent_meta);
-    for (uint32_t i = 0; i < H.n_ent; i++) {
+    for (uint32_t i = 0; i < H.n_ent + H.n_mov; i++) {
         int slot = order[i];   // draw order = type 1 mines in map order, ..., type 21 mines in map order
+        if (slot & 0x8000) continue;   // a mover reference (npp_level.hpp: raster_order)
         if ((meta[slot] & 15u) != EK_MINE) continue;
         double dx = ex[slot] - n.x, dy = ey[slot] - n.y;
         double d = dsqrt(dx * dx + dy * dy);

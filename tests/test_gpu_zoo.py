@@ -245,3 +245,65 @@ def test_all_130_replays_validate_in_one_batch(golden):
         assert (r["x"], r["y"]) == (final[i, 2], final[i, 3]), (i, r, final[i])
         wins += r["won"]
     assert len(res) == 130 and wins == int(np.sum(final[:, 1] == 8)) == 128
+
+
+def test_zoo_edge_cases(golden, oracle_mod):
+    """One env; spatial_context + terminal observation together with the zoo blocks in LDS; truncation; masked reset
+    (a reset is a Simulator.reset(): the entities are no longer in their first creation)."""
+    c, z = golden.z("corpus"), golden.z("zoo")
+    i0 = int(z["idx"][0])
+    m = c["m%d" % i0].astype(np.float64)
+    # (a) a single env replaying its own inputs
+    b = _batch(1, autoreset=False)
+    b.load_levels([m])
+    b.assign_levels(np.array([0]))
+    T = len(z["t%d" % i0])
+    b.tick(torch.from_numpy(c["in%d" % i0][:T].reshape(T, 1).copy()).cuda())
+    f, di = b.dump_state()
+    assert np.array_equal(f[0, :4], z["t%d" % i0][-1]) and di[0, 0] == 8
+    # (b) spatial_context on zoo levels, with auto-reset and terminal observations, against the oracle twin
+    n = 40
+    lv = [c["m%d" % int(k)].astype(np.float64) for k in z["idx"][:4]]
+    b = _batch(n, autoreset=True)
+    b.load_levels(lv)
+    lvl = np.arange(n) % 4
+    b.assign_levels(lvl)
+    b.enable_spatial_context()
+    b.set_truncation_limit(90)
+    rng = np.random.default_rng(8)
+    acts = rng.integers(0, 6, size=(50, n)).astype(np.uint8)
+    d = torch.from_numpy(acts).cuda()
+    sims = []
+    for e in range(n):
+        o = oracle_mod.Oracle("mul")
+        o.load(lv[lvl[e]])
+        sims.append(o)
+    truncated = 0
+    for s in range(50):
+        b.step(d[s])
+        fl = b.flags.cpu().numpy()
+        sc = b.spatial_context.cpu().numpy()
+        f, di = b.dump_state()
+        for e in range(n):
+            _, ofl = sims[e].env_step(int(acts[s, e]), 4)
+            trunc = (not ofl) and sims[e].frame >= 90
+            assert bool(fl[e] & 8) == trunc and bool(fl[e] & 3) == bool(ofl), (s, e, fl[e], ofl, sims[e].frame)
+            truncated += trunc
+            if ofl or trunc:
+                sims[e].reset()
+            assert np.array_equal(f[e], sims[e].core()[0]), (s, e)
+            assert np.array_equal(sc[e], sims[e].spatial_context()), (s, e)
+    assert truncated > 0
+    # (c) masked reset: reset envs restart from spawn with re-created entities, the others are untouched
+    f0, i0_ = b.dump_state()
+    c0 = b.entity_checksum()
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[::2] = 1
+    b.reset(mask)
+    f1, i1 = b.dump_state()
+    c1 = b.entity_checksum()
+    assert np.array_equal(f1[1::2], f0[1::2]) and np.array_equal(c1[1::2], c0[1::2])
+    for e in range(0, n, 2):
+        o = oracle_mod.Oracle("mul")
+        o.load(lv[lvl[e]])
+        assert np.array_equal(f1[e], o.core()[0]) and np.array_equal(c1[e], o.entity_checksum())
