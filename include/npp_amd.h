@@ -125,6 +125,13 @@ int npp_observe(npp_handle h, const npp_step_out *out);
 /* player_frame (84x84 u8) around each ninja, rasterised on device (nsim_renderer.py:71-134 +
  * observation_processor.py:207-282 crop incl. its axis swap).  d_out is [N,84,84]. */
 int npp_render_player_frame(npp_handle h, uint8_t *d_out);
+/* Goal-curriculum repositioning (gym_environment/reward_calculation/intermediate_goal_manager.py:698 apply_to_simulator): move
+ * the exit switch (kind 0) or the exit door (kind 1) of ONE env to pixel position (x, y).  Like there, the entity's grid
+ * cell follows (a switch that changes cell is appended to the new cell's list; the door joins its new cell's list when its
+ * switch is hit) and the position survives resets until it is set again; NaN clears it.  Call between episodes.  Envs with
+ * a moved entity run in the zoo kernels (merged neighbourhood walk). */
+int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y);
+
 /* switch_states observation (gym_environment/npp_environment.py:1782-1847): f32[n_envs][25] = up to 5 locked doors x
  * [switch x / 1056, switch y / 600, door x / 1056, door y / 600, collected]; the reference's door position falls back to the
  * switch position (its segment has no `p1`), reproduced.  No runnable reference for this one: parity by source reading. */

@@ -22,7 +22,9 @@ struct npp_handle_s {
     uint32_t *d_u32 = nullptr;
     uint32_t *d_ent = nullptr;
     float *d_sc_cache = nullptr;
-    double *d_zoo = nullptr;   // per-env zoo blocks (NULL unless a loaded level has zoo entities)
+    double *d_zoo = nullptr;   // per-env zoo blocks (always allocated with the levels; at least the 8-word head)
+    std::vector<uint8_t> ovr;  // per env: ZOO_OVR_* flags set through npp_set_entity_pos
+    int n_ovr = 0;
     double *s_zoo = nullptr;
     int zoo_words = 0, zoo_doors = 0, zoo_movers = 0;
     int zoo_active = 0;        // some env is assigned a level with zoo entities
@@ -88,7 +90,7 @@ void plan_geometry(npp_handle h) {
     if (wpb <= 0) wpb = 4;
     if (wpb > 4) wpb = 4;
     while (wpb > 1 && (64 / g) * wpb > h->n) wpb >>= 1;
-    h->zoo_active = 0;
+    h->zoo_active = h->n_ovr > 0 ? 1 : 0;   // repositioned switches / doors are handled by the zoo kernel's merged walk
     if (h->d_zoo)
         for (int e = 0; e < h->n && !h->zoo_active; e++) h->zoo_active = h->levels[h->env_level[e]].has_zoo ? 1 : 0;
     const int zw = h->zoo_active ? h->zoo_words : 0;
@@ -360,11 +362,10 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.n_balls = (uint32_t)L.n_balls;
         H.db_count = L.db_count;
         for (int k = 0; k < 5; k++) H.locked_slots[k] = L.locked_slots[k];
-        if (L.has_zoo) {
-            any_zoo = true;
-            zoo_doors = std::max(zoo_doors, (int)H.n_zdoor);
-            zoo_movers = std::max(zoo_movers, (int)H.n_mov);
-        }
+        if (L.has_zoo) any_zoo = true;
+        // every level's block is initialised by the reset kernel (locked doors have an edge counter too)
+        zoo_doors = std::max(zoo_doors, (int)H.n_zdoor);
+        zoo_movers = std::max(zoo_movers, (int)H.n_mov);
         H.n_seg = (uint32_t)L.segs.size();
         H.n_ent = (uint32_t)L.ent_x.size();
         H.n_words = (uint32_t)L.ent_init_words.size();
@@ -387,13 +388,14 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     hipFree(h->d_ent); h->d_ent = nullptr;
     hipFree(h->d_zoo); h->d_zoo = nullptr;
     hipFree(h->s_zoo); h->s_zoo = nullptr;
-    h->zoo_words = any_zoo ? zoo_words_for(zoo_doors, zoo_movers) : 0;
+    (void)any_zoo;
+    h->zoo_words = zoo_words_for(zoo_doors, zoo_movers);
     h->zoo_doors = zoo_doors;
     h->zoo_movers = zoo_movers;
-    if (any_zoo) {
-        HIP_TRY(h, hipMalloc((void **)&h->d_zoo, sizeof(double) * (size_t)h->zoo_words * h->n));
-        HIP_TRY(h, hipMemset(h->d_zoo, 0, sizeof(double) * (size_t)h->zoo_words * h->n));
-    }
+    HIP_TRY(h, hipMalloc((void **)&h->d_zoo, sizeof(double) * (size_t)h->zoo_words * h->n));
+    HIP_TRY(h, hipMemset(h->d_zoo, 0, sizeof(double) * (size_t)h->zoo_words * h->n));
+    h->ovr.assign(h->n, 0);
+    h->n_ovr = 0;
     HIP_TRY(h, hipMalloc((void **)&h->d_blob, host.size() + 16));
     HIP_TRY(h, hipMemcpy(h->d_blob, host.data(), host.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMalloc((void **)&h->d_hdr, sizeof(LevelHdr) * n_levels));
@@ -425,6 +427,7 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
             return fail(h, NPP_ERR_INVALID, "npp_assign_levels: index out of range");
         h->env_level[e] = level_ids[i];
         mask[e] = 1;
+        if (!h->ovr.empty() && h->ovr[e]) { h->ovr[e] = 0; h->n_ovr--; }   // a new level: nothing is repositioned
     }
     h->assign_gen++;
     plan_geometry(h);
@@ -487,6 +490,33 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_player_frame: no levels loaded");
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_render(a, d_out, (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0, h->stream));
+    return NPP_OK;
+}
+
+int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y) {
+    if (!h || env < 0 || env >= h->n || (kind != 0 && kind != 1)) return fail(h, NPP_ERR_INVALID, "npp_set_entity_pos: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_set_entity_pos: no levels loaded");
+    const CompiledLevel &L = h->levels[h->env_level[env]];
+    if (L.obs_switch < 0) return fail(h, NPP_ERR_STATE, "npp_set_entity_pos: the env's level has no exit switch / door");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double *blk = h->d_zoo + (size_t)env * h->zoo_words;
+    uint64_t w3 = 0;
+    HIP_TRY(h, hipMemcpy(&w3, blk + 3, 8, hipMemcpyDeviceToHost));
+    const bool clear = !(x == x) || !(y == y);   // NaN clears the override
+    const uint32_t bit = kind == 0 ? ZOO_OVR_SWITCH : ZOO_OVR_DOOR;
+    uint32_t flags = (uint32_t)w3;
+    flags = clear ? (flags & ~bit) : (flags | bit);
+    w3 = (w3 & 0xffffffff00000000ull) | flags;
+    HIP_TRY(h, hipMemcpy(blk + 3, &w3, 8, hipMemcpyHostToDevice));
+    if (!clear) {
+        double xy[2] = {x, y};
+        HIP_TRY(h, hipMemcpy(blk + (kind == 0 ? 4 : 6), xy, 16, hipMemcpyHostToDevice));
+    }
+    const uint8_t before = h->ovr[env];
+    h->ovr[env] = (uint8_t)flags;
+    h->n_ovr += (flags != 0) - (before != 0);
+    plan_geometry(h);
     return NPP_OK;
 }
 
@@ -590,7 +620,10 @@ int npp_entity_checksum(npp_handle h, int env0, int count, double *out) {
     const int door_words = (h->zoo_doors + 1) / 2;
     for (int i = 0; i < count; i++) {
         const CompiledLevel &L = h->levels[h->env_level[env0 + i]];
-        const double *blk = L.has_zoo && h->d_zoo ? zb.data() + (size_t)i * h->zoo_words : nullptr;
+        const double *blk = h->d_zoo ? zb.data() + (size_t)i * h->zoo_words : nullptr;
+        uint64_t head3 = 0;
+        if (blk) std::memcpy(&head3, blk + 3, 8);
+        const uint32_t ovr = (uint32_t)head3;
         double sx = 0, sy = 0, svx = 0, svy = 0;
         long code = 0, act = 0;
         for (uint32_t ref : L.dic_order) {
@@ -612,7 +645,9 @@ int npp_entity_checksum(npp_handle h, int env0, int count, double *out) {
                 int s = (int)ref;
                 uint32_t kind = L.ent_meta[s] & 15u;
                 uint32_t st = (w[(size_t)(s >> 4) * count + i] >> ((s & 15) * 2)) & 3u;
-                sx += L.ent_x[s]; sy += L.ent_y[s];
+                if (blk && s == L.obs_switch && (ovr & ZOO_OVR_SWITCH)) { sx += blk[4]; sy += blk[5]; }
+                else if (blk && s == L.obs_door && (ovr & ZOO_OVR_DOOR)) { sx += blk[6]; sy += blk[7]; }
+                else { sx += L.ent_x[s]; sy += L.ent_y[s]; }
                 if (kind == EK_MINE) { code += 5 * st; act += 1; }
                 else if (kind == EK_EXIT) act += 1;                       // the door object itself never deactivates
                 else if (kind == EK_LOCKED) { code += 3 * (st & 1u); act += st & 1u; }

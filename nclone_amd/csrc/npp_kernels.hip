@@ -1429,7 +1429,9 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         zoff = (zoff + 7) & ~(size_t)7;
         z.blk = reinterpret_cast<double *>(smem + zoff) + (size_t)eib * a.zoo_words;
         z.edges = reinterpret_cast<uint32_t *>(smem + zoff + (size_t)epb * a.zoo_words * 8) + (size_t)eib * (2 * EDGE_WORDS_D);
-        z.on = H.has_zoo != 0;
+        const uint32_t ovr = reinterpret_cast<const uint32_t *>(a.zoo + (size_t)e * a.zoo_words + 3)[0];
+        z.on = H.has_zoo != 0 || (ovr & (ZOO_OVR_SWITCH | ZOO_OVR_DOOR)) != 0;
+        z.obs_switch = H.obs_switch; z.obs_door = H.obs_door; z.vsw_cell = -1; z.vdoor_cell = -1;
         z.ent_seq = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_seq);
         z.ent_cell = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_cell);
         z.mov_meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_mov_meta);
@@ -1444,6 +1446,17 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
             for (int k = r; k < used; k += G) z.blk[k] = src[k];
             const uint32_t *esrc = reinterpret_cast<const uint32_t *>(a.blob + H.off_edges);
             for (int k = r; k < 2 * EDGE_WORDS_D; k += G) z.edges[k] = esrc[k];
+            // npp_set_entity_pos: where the exit switch / door sit now (intermediate_goal_manager.py:698)
+            if ((ovr & ZOO_OVR_SWITCH) && H.obs_switch >= 0) {
+                const double *src4 = src + 4;
+                lv.sw_x = src4[0]; lv.sw_y = src4[1];
+                const int c = pos_cell(src4[0], src4[1]);
+                if (c != (int)z.ent_cell[H.obs_switch]) z.vsw_cell = c;
+            }
+            if ((ovr & ZOO_OVR_DOOR) && H.obs_door >= 0) {
+                lv.door_x = src[6]; lv.door_y = src[7];
+                z.vdoor_cell = pos_cell(src[6], src[7]);
+            }
         }
     }
 
@@ -1599,7 +1612,7 @@ __global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
     store_state(a, env, n);
     const uint32_t *init = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
     for (uint32_t w = 0; w < H.n_words; w++) a.ent_bits[(size_t)w * a.n + env] = init[w];
-    if (a.zoo && H.has_zoo) {
+    if (a.zoo) {
         Zoo z;
         z.blk = a.zoo + (size_t)env * a.zoo_words;
         z.edges = nullptr;

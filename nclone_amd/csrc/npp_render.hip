@@ -186,7 +186,13 @@ __device__ int build_draw_list(const KernelArgs &a, const LevelHdr &H, int env, 
             continue;
         }
         const int slot = (int)ref;
-        const float x = (float)ex[slot], y = (float)ey[slot];
+        float x = (float)ex[slot], y = (float)ey[slot];
+        if (a.zoo) {   // npp_set_entity_pos
+            const double *hd = a.zoo + (size_t)env * a.zoo_words;
+            const uint32_t ovr = reinterpret_cast<const uint32_t *>(hd + 3)[0];
+            if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)hd[4]; y = (float)hd[5]; }
+            if (slot == H.obs_door && (ovr & ZOO_OVR_DOOR)) { x = (float)hd[6]; y = (float)hd[7]; }
+        }
         if (x < wx0 || x > wx1 || y < wy0 || y > wy1) continue;
         const uint32_t mm = meta[slot], kind = mm & 15u, type = (mm >> 24) & 63u;
         const uint32_t st = state_of(slot);

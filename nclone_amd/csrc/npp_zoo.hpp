@@ -29,7 +29,9 @@ struct Zoo {
     const uint32_t *door_tab;
     int n_mov, n_door, door_words, n_balls, n_created;
     double db_count;
-    bool on;                  // this env's level has zoo entities
+    bool on;                  // this env's level has zoo entities, or its exit switch / door was repositioned
+    // npp_set_entity_pos: cells of the repositioned exit switch (only when it left its original cell) / exit door, else -1
+    int obs_switch, obs_door, vsw_cell, vdoor_cell;
 };
 
 // per-tick accumulators of pre_collision (ninja.py:217-219)
@@ -44,6 +46,7 @@ DEV double *zoo_mov(const Zoo &z, int m) { return z.blk + ZOO_HEAD + z.door_word
 DEV uint32_t *zoo_mov_w(const Zoo &z, int m) { return reinterpret_cast<uint32_t *>(zoo_mov(z, m) + 4); }
 DEV int *zoo_door(const Zoo &z, int d) { return reinterpret_cast<int *>(z.blk + ZOO_HEAD) + d; }
 DEV uint32_t *zoo_head_w(const Zoo &z) { return reinterpret_cast<uint32_t *>(z.blk + 2); }   // [0] counter, [1] fresh
+DEV uint32_t *zoo_ovr_w(const Zoo &z) { return reinterpret_cast<uint32_t *>(z.blk + 3); }    // [0] ZOO_OVR_* flags, [1] exit door's list-order number
 DEV int door_counter(int v) { return (int)(short)(v & 0xffff); }
 DEV int door_pack(int counter, int timer) { return (counter & 0xffff) | (timer << 16); }
 DEV int pos_cell(double x, double y) { return cell_coord(x, 43) * 25 + cell_coord(y, 24); }
@@ -54,8 +57,10 @@ constexpr uint32_t MKD_DRONE = 1, MKD_BOUNCE = 2, MKD_THWUMP = 3, MKD_BALL = 4, 
 DEV void zoo_init_block(const Zoo &z, int r, int G, bool fresh) {
     if (r == 0) {
         z.blk[0] = 0; z.blk[1] = 0;
-        zoo_head_w(z)[0] = (uint32_t)z.n_created;
+        zoo_head_w(z)[0] = (uint32_t)z.n_created + 1u;   // n_created itself is the number of a repositioned exit switch
         zoo_head_w(z)[1] = fresh ? 1u : 0u;
+        if (fresh) { zoo_ovr_w(z)[0] = 0; z.blk[4] = 0; z.blk[5] = 0; z.blk[6] = 0; z.blk[7] = 0; }   // new level: nothing moved
+        zoo_ovr_w(z)[1] = 0;
     }
     for (int d = r; d < z.n_door; d += G) *zoo_door(z, d) = door_pack((int)z.door_tab[2 * d + 1], 0);
     for (int m = r; m < z.n_mov; m += G) {
@@ -507,6 +512,20 @@ DEV int zoo_next(const Zoo &z, int r, int lo, int hi, int x0, int x1, int y0, in
         const int key = zoo_key(cell, w[1]);
         if (key > lo && key < hi && key < best) { best = key; slot = m; }
     }
+    if (!phys) {
+        // a repositioned exit switch that left its cell was appended to the new cell's list right after level load (number
+        // n_created); the exit door joins its cell's list when the switch is hit (number taken then).  Slots n_mov, n_mov + 1.
+        if (z.vsw_cell >= 0) {
+            const int cx = z.vsw_cell / 25, cy = z.vsw_cell - cx * 25;
+            const int key = zoo_key(z.vsw_cell, (uint32_t)z.n_created);
+            if (cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1 && key > lo && key < hi && key < best) { best = key; slot = z.n_mov; }
+        }
+        if (z.vdoor_cell >= 0 && zoo_ovr_w(z)[1] != 0) {
+            const int cx = z.vdoor_cell / 25, cy = z.vdoor_cell - cx * 25;
+            const int key = zoo_key(z.vdoor_cell, zoo_ovr_w(z)[1]);
+            if (cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1 && key > lo && key < hi && key < best) { best = key; slot = z.n_mov + 1; }
+        }
+    }
     const int kmin = group_min_i<G>(best);
     if (kmin == 0x7fffffff) return -1;
     const int s = group_min_i<G>(best == kmin ? slot : 0x7fffffff);
@@ -697,7 +716,21 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
     int pend0 = -1, pend1 = -1;
     double wall_normal = 0;
     int nk = 0;
-    int nm = z.n_mov ? zoo_next<G>(z, r, -1, 0x7fffffff, x0, x1, y0, y1, false, nk) : -1;
+    int nm = (z.n_mov || z.vsw_cell >= 0 || z.vdoor_cell >= 0) ? zoo_next<G>(z, r, -1, 0x7fffffff, x0, x1, y0, y1, false, nk) : -1;
+    // a mover, or one of the two repositioned entities (slots n_mov: exit switch, n_mov + 1: exit door)
+    auto visit = [&](int m) {
+        if (m < z.n_mov) { mover_logical(z, m, n, wall_normal); return; }
+        if (m == z.n_mov) {   // entity_exit_switch.py:67-129 at its new place
+            if (ent_get(eb, z.obs_switch) == 1 && overlaps(z.blk[4], z.blk[5], 6.0 + NINJA_RADIUS, n.x, n.y)) {
+                ent_set(eb, z.obs_switch, 0);
+                zoo_ovr_w(z)[1] = zoo_head_w(z)[0];
+                zoo_head_w(z)[0] += 1;
+                if (pend0 < 0) pend0 = z.obs_door; else pend1 = z.obs_door;
+            }
+        } else if (ent_get(eb, z.obs_door) == 1) {   // entity_exit.py:66-74 at its new place
+            if (overlaps(z.blk[6], z.blk[7], 12.0 + NINJA_RADIUS, n.x, n.y)) ninja_win(n);
+        }
+    };
     for (int xc = x0; xc <= x1; xc++) {
         const int i0 = lv.ent_start[xc * 25 + y0], i1 = lv.ent_start[xc * 25 + y1 + 1];
         for (int i = i0; i < i1; i++) {
@@ -705,15 +738,18 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
             const uint32_t kind = meta & 15u;
             const uint32_t st = ent_get(eb, i);
             if (kind == EK_EXIT && st == 0) continue;   // not in the grid: it does not even take a place in the order
+            if ((i == z.obs_switch && z.vsw_cell >= 0) || (i == z.obs_door && z.vdoor_cell >= 0)) continue;   // lives elsewhere now
             if (nm >= 0) {
-                const int key = zoo_key(z.ent_cell[i], z.ent_seq[i]);
+                // the exit door was appended to its cell's list when its switch was hit: it carries that number
+                const int key = zoo_key(z.ent_cell[i], (i == z.obs_door && zoo_ovr_w(z)[1] != 0) ? zoo_ovr_w(z)[1] : (uint32_t)z.ent_seq[i]);
                 while (nm >= 0 && nk < key) {
-                    mover_logical(z, nm, n, wall_normal);
+                    visit(nm);
                     const int last = nk;
                     nm = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, false, nk);
                 }
             }
-            const double ex = lv.ent_x[i], ey = lv.ent_y[i];
+            double ex = lv.ent_x[i], ey = lv.ent_y[i];
+            if (i == z.obs_switch && (zoo_ovr_w(z)[0] & ZOO_OVR_SWITCH)) { ex = z.blk[4]; ey = z.blk[5]; }   // moved inside its cell
             if (kind == EK_MINE) {   // entity_toggle_mine.py:120-128
                 if (valid_target(n.state) && st == 0 && overlaps(ex, ey, 4.0 + NINJA_RADIUS, n.x, n.y)) {
                     ent_set(eb, i, 1);
@@ -729,6 +765,10 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
                 if (overlaps(ex, ey, 6.0 + NINJA_RADIUS, n.x, n.y)) {
                     ent_set(eb, i, 0);
                     const int door = (int)((meta >> 8) & 0xffffu);
+                    if (door == z.obs_door) {   // list-order number of the append (entity_exit_switch.py:120)
+                        zoo_ovr_w(z)[1] = zoo_head_w(z)[0];
+                        zoo_head_w(z)[0] += 1;
+                    }
                     if (pend0 < 0) pend0 = door; else pend1 = door;
                 }
             } else if (kind == EK_LOCKED) {   // entity_door_locked.py:54-67
@@ -779,7 +819,7 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
         }
     }
     while (nm >= 0) {
-        mover_logical(z, nm, n, wall_normal);
+        visit(nm);
         const int last = nk;
         nm = zoo_next<G>(z, r, last, 0x7fffffff, x0, x1, y0, y1, false, nk);
     }

@@ -143,6 +143,10 @@ class NppBatch:
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 84 * 84 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_render_player_frame(self.h, C.c_void_p(out.data_ptr())))
 
+    def set_entity_pos(self, env, kind, x, y):
+        """Move the exit switch (kind 0) or exit door (kind 1) of one env (curriculum repositioning); NaN clears."""
+        nat.check(self.h, self.lib.npp_set_entity_pos(self.h, int(env), int(kind), float(x), float(y)))
+
     def switch_states(self, out=None):
         """float32 CUDA tensor [N, 25]: the reference's switch_states observation (5 locked doors x 5 features)."""
         if out is None:

@@ -207,6 +207,10 @@ typedef struct OSim {
     int has_zoo;              /* any movable / physically collidable / extra thinkable entity */
     int creations;            /* number of times the entities were (re)created since load: sim.entity_counts persists
                                  across Simulator.reset(), so Entity.index keeps growing (entities.py:129-133) */
+    /* curriculum repositioning of the exit switch [0] / exit door [1] (intermediate_goal_manager.py:698), re-applied after
+     * every reset like the reference does after every map load */
+    int ovr_set[2];
+    double ovr_x[2], ovr_y[2];
     Entity *cached[256];      /* ninja._cached_entities (ninja.py:220-222) */
     int ncached;
     /* mine-overlay cache of gym_environment/spatial_context.py:103-110,309-367 (per env = per process there) */
@@ -594,6 +598,40 @@ static void ninja_init(OSim *S)
     n->ceiling_normalized_y = 1;
 }
 
+/* intermediate_goal_manager.py:698-1000 apply_to_simulator: the LAST EntityExitSwitch of entity_dic[3] and its parent door get
+ * new positions; a switch that changes cell leaves its list and is appended to the new cell's list; the door only gets its
+ * new cell (it joins that cell's list when the switch is hit, entity_exit_switch.py:120) */
+static void apply_overrides(OSim *S)
+{
+    Entity *sw = NULL;
+    for (int i = S->ndic - 1; i >= 0 && !sw; i--)
+        if (S->dic_order[i]->kind == K_SWITCH) sw = S->dic_order[i];
+    if (!sw) return;
+    if (S->ovr_set[0]) {
+        sw->x = S->ovr_x[0]; sw->y = S->ovr_y[0];
+        int ncx = iclamp((int)floor(sw->x / 24), 0, 43), ncy = iclamp((int)floor(sw->y / 24), 0, 24);
+        if (ncx != sw->cx || ncy != sw->cy) {
+            EList *l = &S->grid[sw->cx][sw->cy];
+            for (int k = 0; k < l->n; k++)
+                if (l->e[k] == sw) { memmove(&l->e[k], &l->e[k + 1], sizeof(Entity *) * (l->n - k - 1)); l->n--; break; }
+            sw->cx = ncx; sw->cy = ncy;
+            elist_push(&S->grid[ncx][ncy], sw);
+        }
+    }
+    if (S->ovr_set[1] && sw->parent) {
+        Entity *d = sw->parent;
+        d->x = S->ovr_x[1]; d->y = S->ovr_y[1];
+        d->cx = iclamp((int)floor(d->x / 24), 0, 43); d->cy = iclamp((int)floor(d->y / 24), 0, 24);
+    }
+}
+
+void osim_set_entity_pos(OSim *S, int kind, double x, double y)
+{
+    if (kind < 0 || kind > 1) return;
+    S->ovr_set[kind] = 1; S->ovr_x[kind] = x; S->ovr_y[kind] = y;
+    apply_overrides(S);
+}
+
 void osim_reset(OSim *S)
 {
     /* nsim.py:62-76: Simulator.reset() re-creates every entity from map_data (the semantics restated here;
@@ -628,6 +666,7 @@ void osim_reset(OSim *S)
         }
     }
     grid_rebuild(S);
+    apply_overrides(S);
 }
 
 OSim *osim_create(void) { return calloc(1, sizeof(OSim)); }
@@ -664,6 +703,7 @@ int osim_load(OSim *S, const double *map, int n)
     build_geometry(S);
     load_entities(S);
     S->creations = 0;   /* a load restated here is a fresh Simulator */
+    S->ovr_set[0] = S->ovr_set[1] = 0;
     osim_reset(S);
     return S->unsupported;
 }

@@ -62,6 +62,7 @@ def _lib(variant):
     lib.osim_dump_entities.restype = C.c_int
     lib.osim_entity_states.argtypes = [P, C.POINTER(C.c_int), C.c_int]
     lib.osim_entity_states.restype = C.c_int
+    lib.osim_set_entity_pos.argtypes = [P, C.c_int, C.c_double, C.c_double]
     lib.osim_dump_draw.argtypes = [P, C.POINTER(C.c_double), C.c_int]
     lib.osim_dump_draw.restype = C.c_int
     lib.osim_dump_edges.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -142,6 +143,10 @@ class Oracle:
         n = self.lib.osim_dump_entities(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), len(buf))
         assert n >= 0
         return buf[:n].copy()
+
+    def set_entity_pos(self, kind, x, y):
+        """Curriculum repositioning of the exit switch (0) / exit door (1); survives resets."""
+        self.lib.osim_set_entity_pos(self.h, int(kind), float(x), float(y))
 
     def draw_list(self):
         """[n, 13] rows of what the entity layer would draw, entity_dic order (see osim_dump_draw)."""

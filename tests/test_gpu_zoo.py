@@ -307,3 +307,54 @@ def test_zoo_edge_cases(golden, oracle_mod):
         o = oracle_mod.Oracle("mul")
         o.load(lv[lvl[e]])
         assert np.array_equal(f1[e], o.core()[0]) and np.array_equal(c1[e], o.entity_checksum())
+
+
+def test_set_entity_pos_matches_reference(golden, oracle_mod):
+    """npp_set_entity_pos (curriculum repositioning, intermediate_goal_manager.py:698): exit switch and exit door moved onto
+    the recorded trajectory of 8 replays (plain, mines and zoo levels); fixtures from the reference simulator
+    (make_golden_moved.py).  Two episodes with a reset in between (positions persist); plus one untouched env per level
+    in the same batch, which must still reproduce the original replay."""
+    c, mv = golden.z("corpus"), golden.z("moved")
+    idx = [int(i) for i in mv["idx"]]
+    n = 2 * len(idx)
+    b = _batch(n, autoreset=False)
+    b.load_levels([c["m%d" % i] for i in idx])
+    b.assign_levels(np.arange(n) % len(idx))
+    for k, i in enumerate(idx):
+        b.set_entity_pos(k, 0, *mv["sw%d" % i])
+        b.set_entity_pos(k, 1, *mv["door%d" % i])
+    final = c["final"]
+    for ep in range(2):
+        T = [int(mv["ep%d" % i][0]) if ep == 0 else len(mv["t%d" % i]) - int(mv["ep%d" % i][0]) for i in idx]
+        base = [0 if ep == 0 else int(mv["ep%d" % i][0]) for i in idx]
+        tmax = max(max(T), max(int(final[i, 0]) for i in idx) if ep == 0 else 0)
+        inputs = np.zeros((tmax, n), dtype=np.uint8)
+        for e in range(n):
+            i = idx[e % len(idx)]
+            seq = c["in%d" % i]
+            m = min(tmax, len(seq))
+            inputs[:m, e] = seq[:m]
+        d_in = torch.from_numpy(inputs).cuda()
+        done = np.zeros(n, dtype=bool)
+        for tick in range(tmax):
+            b.tick(d_in[tick : tick + 1])
+            f, di = b.dump_state()
+            for k, i in enumerate(idx):
+                if tick < T[k]:
+                    ref = mv["t%d" % i][base[k] + tick]
+                    assert np.array_equal(f[k, :4], ref), (ep, i, tick, f[k, :4], ref)
+                    assert np.array_equal(_disc(di[k : k + 1])[0], mv["d%d" % i][base[k] + tick]), (ep, i, tick)
+                    if tick == T[k] - 1:
+                        assert di[k, 0] == 8
+                if ep == 0:
+                    e = k + len(idx)      # the untouched twin
+                    if tick == int(final[i, 0]) - 1:
+                        assert di[e, 0] == int(final[i, 1]) and np.array_equal(f[e, :2], final[i, 2:4]), (i, tick)
+        b.reset()
+    # entity_positions observation reports the moved switch / door
+    b.observe()
+    ep_ = b.entity_pos.cpu().numpy()
+    for k, i in enumerate(idx):
+        sw, door = mv["sw%d" % i], mv["door%d" % i]
+        want = np.array([sw[0] / 1056.0, sw[1] / 600.0, door[0] / 1056.0, door[1] / 600.0], dtype=np.float32)
+        assert np.allclose(ep_[k, 2:6], want, atol=1e-7), (i, ep_[k], want)

@@ -186,6 +186,34 @@ def test_oracle_zoo_rollouts(golden, oracle_mod):
                 o.reset()
 
 
+@pytest.mark.parametrize("variant", ["pow", "mul"])
+def test_oracle_repositioned_switch_and_door(golden, oracle_mod, variant):
+    """Curriculum repositioning (intermediate_goal_manager.py:698): exit switch and door moved onto the recorded trajectory
+    (moved.npz from make_golden_moved.py, produced by the reference simulator with the same attribute updates), two
+    episodes with a Simulator.reset() in between; every tick of both."""
+    c, mv = golden.z("corpus"), golden.z("moved")
+    for i in mv["idx"]:
+        o = oracle_mod.Oracle(variant)
+        o.load(c["m%d" % i].astype(np.float64))
+        o.set_entity_pos(0, *mv["sw%d" % i])
+        o.set_entity_pos(1, *mv["door%d" % i])
+        T, D, ep1 = mv["t%d" % i], mv["d%d" % i], int(mv["ep%d" % i][0])
+        k = 0
+        for ep in range(2):
+            for b in c["in%d" % i]:
+                h, j = oracle_mod.controls(int(b))
+                o.tick(h, j)
+                f, d = o.core()
+                assert np.array_equal(f[:4], T[k]), (i, ep, k, f[:4], T[k])
+                assert np.array_equal(d[:20].clip(0, 255), D[k]), (i, ep, k)
+                k += 1
+                if d[0] in (6, 7, 8):
+                    break
+            assert k == (ep1 if ep == 0 else len(T)), (i, ep, k)
+            o.reset()
+        assert D[-1][0] == 8
+
+
 def test_oracle_spatial_context(golden, oracle_mod):
     """spatial_context rows from the reference's spatial_context.py (loaded by file, see make_golden.py)."""
     r = golden.z("rollouts")
