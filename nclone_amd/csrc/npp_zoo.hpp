@@ -403,6 +403,31 @@ __device__ __noinline__ Best closest_generic(TileRefs lv, int r, double px, doub
     return m;
 }
 
+// get_single_closest_point (physics.py:131-180) answered from candidate registers: the query's own region (cell filter with
+// the inclusive cell-bounds test) and per-segment AABB both use the box q = position +- radius; first-wins argmin in the
+// reference's iteration order (the gather order).  Same per-candidate arithmetic as the ninja's depenetration loop.
+template <int G, int K>
+DEV Best cand_closest_query(const Cand<K> &cd, int r, double px, double py, const QBox &q) {
+    Best m;
+    m.key = __builtin_inf(); m.idx = 0x7fffffff; m.a = 0; m.b = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (!cand_in_box(cd, k, q)) continue;
+        const double bx0 = __builtin_fmin(cd.x1[k], cd.x2[k]), bx1 = __builtin_fmax(cd.x1[k], cd.x2[k]);
+        const double by0 = __builtin_fmin(cd.y1[k], cd.y2[k]), by1 = __builtin_fmax(cd.y1[k], cd.y2[k]);
+        if ((bx1 < q.x0) | (bx0 > q.x1) | (by1 < q.y0) | (by0 > q.y1)) continue;
+        double a, b;
+        bool back;
+        if ((cd.s[k] & 1u) == 0) back = cand_closest_lin(cd, k, px, py, a, b);
+        else back = cand_closest_arc(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], px, py, a, b);
+        const double distance_sq = sq(px - a) + sq(py - b);
+        const double key = back ? distance_sq : distance_sq - 0.1;
+        if (key < m.key) { m.key = key; m.a = a; m.b = b; m.idx = ((k * G + r) << 8) | (r << 1) | (back ? 1 : 0); }
+    }
+    group_argmin<G>(m);
+    return m;
+}
+
 // entity_death_ball.py:74-167 for ball slot m; all lanes of the group cooperate on the tile queries.  Returns true when
 // grid_move changed the cell.
 template <int G>
@@ -430,34 +455,61 @@ DEV bool ball_think(const Lv &lv, const Zoo &z, int r, const Nj &n, int m, int b
     const TileRefs tr{lv.seg_start, lv.segs, lv.bounds};
     // cells that the sweep (radius 4 + 1) and the first closest-point query (radius 8) can look at: when they hold no
     // segment at all, the sweep returns 1 and the query returns "nothing" (physics.py:116-128, 141-180)
+    const double xn = xold + vx, yn = yold + vy;
+    const double ux0 = (xold < xn ? xold : xn), ux1 = (xold > xn ? xold : xn), uy0 = (yold < yn ? yold : yn), uy1 = (yold > yn ? yold : yn);
     bool open_space;
     {
-        const double xn = xold + vx, yn = yold + vy;
-        const int c0x = cell_coord((xold < xn ? xold : xn) - 8, 43), c1x = cell_coord((xold > xn ? xold : xn) + 8, 43);
-        const int c0y = cell_coord((yold < yn ? yold : yn) - 8, 24), c1y = cell_coord((yold > yn ? yold : yn) + 8, 24);
+        const int c0x = cell_coord(ux0 - 8, 43), c1x = cell_coord(ux1 + 8, 43), c0y = cell_coord(uy0 - 8, 24), c1y = cell_coord(uy1 + 8, 24);
         int nseg = 0;
         for (int xc = c0x; xc <= c1x; xc++) nseg += (int)lv.seg_start[xc * 25 + c1y + 1] - (int)lv.seg_start[xc * 25 + c0y];
         open_space = nseg == 0;
     }
-    const double time = open_space ? 1.0 : sweep_generic<G>(tr, r, xold, yold, vx, vy, 8 * 0.5);
-    x = xold + time * vx;
-    y = yold + time * vy;
     double xnormal = 0, ynormal = 0;
     bool bail = false;
-    for (int it = 0; it < (open_space ? 0 : 16); it++) {
-        const Best c = closest_generic<G>(tr, r, x, y, 8.0);
-        if (c.idx == 0x7fffffff) break;
-        const int result = (c.idx & 1) ? -1 : 1;
-        const double dx = x - c.a, dy = y - c.b;
-        const double dist = dsqrt(sq(dx) + sq(dy));
-        const double depen_len = 8 - dist * result;
-        if (depen_len < 0.0000001) break;
-        if (dist == 0) { bail = true; break; }   // `return` in the reference: nothing below runs
-        const double xnorm = dx / dist, ynorm = dy / dist;
-        x += xnorm * depen_len;
-        y += ynorm * depen_len;
-        xnormal += xnorm;
-        ynormal += ynorm;
+    if (open_space) {
+        x = xn; y = yn;
+    } else {
+        // like the ninja's tick: gather the segments around the ball's path once into registers and answer the sweep and
+        // every closest-point query from them; a query that leaves the gathered cells takes the table walk
+        constexpr int K = KSlots<G>::value;
+        Cand<K> cd;
+        cand_gather<G, K>(lv, r, ux0 - 10.0, uy0 - 10.0, ux1 + 10.0, uy1 + 10.0, cd);
+        double time = 1;
+        {
+            const double radius = 8 * 0.5, width = radius + 1;
+            const QBox q = make_qbox(ux0 - width, uy0 - width, ux1 + width, uy1 + width);
+            if (cand_covers(cd, q)) {
+                const double vel_sq = sq(vx) + sq(vy);
+                double shortest = 1;
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (cand_in_box(cd, k, q)) {
+                        const double t = cand_toi(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], xold, yold, vx, vy, vel_sq, radius);
+                        if (t < shortest) shortest = t;
+                    }
+                time = group_min<G>(shortest);
+            } else {
+                time = sweep_generic<G>(tr, r, xold, yold, vx, vy, radius);
+            }
+        }
+        x = xold + time * vx;
+        y = yold + time * vy;
+        for (int it = 0; it < 16; it++) {
+            const QBox q = make_qbox(x - 8.0, y - 8.0, x + 8.0, y + 8.0);
+            const Best c = cand_covers(cd, q) ? cand_closest_query<G, K>(cd, r, x, y, q) : closest_generic<G>(tr, r, x, y, 8.0);
+            if (c.idx == 0x7fffffff) break;
+            const int result = (c.idx & 1) ? -1 : 1;
+            const double dx = x - c.a, dy = y - c.b;
+            const double dist = dsqrt(sq(dx) + sq(dy));
+            const double depen_len = 8 - dist * result;
+            if (depen_len < 0.0000001) break;
+            if (dist == 0) { bail = true; break; }   // `return` in the reference: nothing below runs
+            const double xnorm = dx / dist, ynorm = dy / dist;
+            x += xnorm * depen_len;
+            y += ynorm * depen_len;
+            xnormal += xnorm;
+            ynormal += ynorm;
+        }
     }
     if (!bail) {
         const double normal_len = dsqrt(sq(xnormal) + sq(ynormal));
