@@ -103,6 +103,7 @@ void plan_geometry(npp_handle h) {
             if (g < 64) { g *= 2; continue; }   // zoo blocks are big: fewer envs per wavefront
         }
         uint32_t cap = h->hot_max;
+        if (zw && fixed + cap > LDS_BUDGET && wpb > 1) { wpb >>= 1; continue; }   // zoo: staging the level beats a bigger workgroup
         if (fixed + cap > LDS_BUDGET) cap = fixed < LDS_BUDGET ? ((LDS_BUDGET - fixed) / 16) * 16 : 0;
         h->lds_hot_cap = cap;
         break;
@@ -360,6 +361,9 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.n_zdoor = (uint32_t)(L.door_tab.size() / 2);
         H.n_created = (uint32_t)L.n_created;
         H.n_balls = (uint32_t)L.n_balls;
+        H.ball_first = 0;
+        for (size_t m = 0; m < L.mov_meta.size(); m++)
+            if ((L.mov_meta[m] & 7u) == MK_BALL) { H.ball_first = (uint32_t)m; break; }
         H.db_count = L.db_count;
         for (int k = 0; k < 5; k++) H.locked_slots[k] = L.locked_slots[k];
         if (L.has_zoo) any_zoo = true;

@@ -45,6 +45,8 @@ struct LevelHdr {
     uint32_t n_zdoor;
     uint32_t n_created;
     uint32_t n_balls;
+    uint32_t ball_first;    // mover slot of the first death ball
+    uint32_t pad2_;
     double db_count;
     int32_t locked_slots[5];   // CSR slots of the first five locked doors (entity_dic[6] order), -1 = none
     int32_t pad_;

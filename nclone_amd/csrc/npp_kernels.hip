@@ -1439,7 +1439,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         z.mov_y0 = reinterpret_cast<const double *>(a.blob + H.off_mov_y0);
         z.door_tab = reinterpret_cast<const uint32_t *>(a.blob + H.off_door_tab);
         z.n_mov = (int)H.n_mov; z.n_door = (int)H.n_zdoor; z.door_words = (a.zoo_doors + 1) / 2;
-        z.n_balls = (int)H.n_balls; z.n_created = (int)H.n_created; z.db_count = H.db_count;
+        z.n_balls = (int)H.n_balls; z.n_created = (int)H.n_created; z.db_count = H.db_count; z.ball_first = (int)H.ball_first;
         if (z.on) {
             const int used = ZOO_HEAD + z.door_words + ZOO_MOV_WORDS * z.n_mov;
             const double *src = a.zoo + (size_t)e * a.zoo_words;
@@ -1646,9 +1646,10 @@ hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
     const int wpb = a.waves_per_block;
     const int epb = (WAVE / G) * wpb;
     const int blocks = (a.n + epb - 1) / epb;
-    if (a.zoo_active) {   // zoo levels: level tables stay in L1/L2, LDS holds the per-env zoo blocks
-        const size_t lds = lds_bytes(0, a.n_words_max, epb, a.zoo_words);
-        hipLaunchKernelGGL((npp_step_kernel<G, false, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
+    if (a.zoo_active) {   // zoo levels: LDS also holds the per-env zoo blocks
+        const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb, a.zoo_words);
+        if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
+        else hipLaunchKernelGGL((npp_step_kernel<G, false, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
         return hipGetLastError();
     }
     const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb);

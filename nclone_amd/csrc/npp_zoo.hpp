@@ -27,7 +27,7 @@ struct Zoo {
     const double *mov_x0;
     const double *mov_y0;
     const uint32_t *door_tab;
-    int n_mov, n_door, door_words, n_balls, n_created;
+    int n_mov, n_door, door_words, n_balls, n_created, ball_first;
     double db_count;
     bool on;                  // this env's level has zoo entities, or its exit switch / door was repositioned
     // npp_set_entity_pos: cells of the repositioned exit switch (only when it left its original cell) / exit door, else -1
@@ -47,6 +47,11 @@ DEV uint32_t *zoo_mov_w(const Zoo &z, int m) { return reinterpret_cast<uint32_t 
 DEV int *zoo_door(const Zoo &z, int d) { return reinterpret_cast<int *>(z.blk + ZOO_HEAD) + d; }
 DEV uint32_t *zoo_head_w(const Zoo &z) { return reinterpret_cast<uint32_t *>(z.blk + 2); }   // [0] counter, [1] fresh
 DEV uint32_t *zoo_ovr_w(const Zoo &z) { return reinterpret_cast<uint32_t *>(z.blk + 3); }    // [0] ZOO_OVR_* flags, [1] exit door's list-order number
+// static mover attributes are mirrored into the LDS record (bits 17-19 kind, 20-22 orientation, 23-24 mode of word 0) so that
+// the per-tick passes never go to the level tables in global memory for them
+DEV uint32_t mov_kind(const Zoo &z, int m) { return (zoo_mov_w(z, m)[0] >> 17) & 7u; }
+DEV uint32_t mov_orient(const Zoo &z, int m) { return (zoo_mov_w(z, m)[0] >> 20) & 7u; }
+DEV uint32_t mov_mode(const Zoo &z, int m) { return (zoo_mov_w(z, m)[0] >> 23) & 3u; }
 DEV int door_counter(int v) { return (int)(short)(v & 0xffff); }
 DEV int door_pack(int counter, int timer) { return (counter & 0xffff) | (timer << 16); }
 DEV int pos_cell(double x, double y) { return cell_coord(x, 43) * 25 + cell_coord(y, 24); }
@@ -74,7 +79,7 @@ DEV void zoo_init_block(const Zoo &z, int r, int G, bool fresh) {
         else { p[2] = 0; p[3] = 0; }
         if (kind == MKD_THWUMP) bits = 1;   // state + 1
         uint32_t *w = zoo_mov_w(z, m);
-        w[0] = (uint32_t)pos_cell(x, y) | (bits << 11);
+        w[0] = (uint32_t)pos_cell(x, y) | (bits << 11) | (kind << 17) | (orient << 20) | (((meta >> 6) & 3u) << 23);
         w[1] = meta >> 8;
     }
 }
@@ -182,15 +187,14 @@ DEV bool drone_test(const Zoo &z, double x, double y, int dir, double R, double 
 // One mover's move() (nsim.py:246-247).  Returns true when Entity.grid_move put it into another cell (the caller
 // assigns the list-order number); `newcell` is that cell.
 DEV bool mover_move(const Zoo &z, int m, int &newcell) {
-    const uint32_t meta = z.mov_meta[m];
-    const uint32_t kind = meta & 7u;
+    const uint32_t kind = mov_kind(z, m);
     double *p = zoo_mov(z, m);
     uint32_t *w = zoo_mov_w(z, m);
     const int cell = (int)(w[0] & 0x7ffu);
     bool gm = false;   // reached Entity.grid_move
     if (kind == MKD_DRONE || kind == MKD_MINI) {   // entity_drone_base.py:93-136
         const double speed = kind == MKD_DRONE ? 8.0 / 7 : 1.3, R = kind == MKD_DRONE ? 7.5 : 4.0, grid = kind == MKD_DRONE ? 24.0 : 12.0;
-        const int mode = (int)((meta >> 6) & 3u);
+        const int mode = (int)mov_mode(z, m);
         int dir = (int)((w[0] >> 11) & 3u);
         double x = p[0], y = p[1], xt = p[2], yt = p[3];
         const double xspeed = speed * dir_vx(dir), yspeed = speed * dir_vy(dir);
@@ -228,7 +232,7 @@ DEV bool mover_move(const Zoo &z, int m, int &newcell) {
     } else if (kind == MKD_THWUMP) {   // entity_thwump.py:109-156
         int state = (int)((w[0] >> 11) & 3u) - 1;
         if (state) {
-            const uint32_t orient = (meta >> 3) & 7u;
+            const uint32_t orient = mov_orient(z, m);
             const bool horizontal = (orient == 0 || orient == 4);
             const int direction = (orient == 0 || orient == 2) ? 1 : -1;
             const double speed = state == 1 ? 20.0 / 7 : 8.0 / 7;
@@ -290,7 +294,7 @@ DEV void thwump_think(const Zoo &z, int m, const Nj &n) {
     uint32_t *w = zoo_mov_w(z, m);
     const int state = (int)((w[0] >> 11) & 3u) - 1;
     if (state || !valid_target(n.state)) return;
-    const uint32_t orient = (z.mov_meta[m] >> 3) & 7u;
+    const uint32_t orient = mov_orient(z, m);
     const bool horizontal = (orient == 0 || orient == 4);
     const int direction = (orient == 0 || orient == 2) ? 1 : -1;
     const double *p = zoo_mov(z, m);
@@ -555,7 +559,7 @@ template <int G>
 DEV int zoo_next(const Zoo &z, int r, int lo, int hi, int x0, int x1, int y0, int y1, bool phys, int &key_out) {
     int best = 0x7fffffff, slot = 0x7fffffff;
     for (int m = r; m < z.n_mov; m += G) {
-        const uint32_t kind = z.mov_meta[m] & 7u;
+        const uint32_t kind = mov_kind(z, m);
         if (phys && !(kind == MKD_BOUNCE || kind == MKD_THWUMP || kind == MKD_SHOVE)) continue;
         const uint32_t *w = zoo_mov_w(z, m);
         const int cell = (int)(w[0] & 0x7ffu);
@@ -626,7 +630,7 @@ DEV void apply_physical(Nj &n, ZTick &zt, int type, double depen_x, double depen
 
 // physical_collision() of a mover (entity_bounce_block.py:127-145, entity_thwump.py:208-213, entity_shove_thwump.py:155-171)
 DEV void mover_physical(const Zoo &z, int m, Nj &n, ZTick &zt, double &fnsx, double &fnsy, double &cnsx, double &cnsy) {
-    const uint32_t kind = z.mov_meta[m] & 7u;
+    const uint32_t kind = mov_kind(z, m);
     double *p = zoo_mov(z, m);
     double nx, ny, len, len2;
     if (kind == MKD_BOUNCE) {
@@ -703,7 +707,7 @@ DEV void collide_vs_objects(const Lv &lv, const Zoo &z, int r, Nj &n, ZTick &zt,
 
 // logical_collision() of a mover; adds to wall_normal what the reference's post_collision would (ninja.py:419-420)
 DEV void mover_logical(const Zoo &z, int m, Nj &n, double &wall_normal) {
-    const uint32_t kind = z.mov_meta[m] & 7u;
+    const uint32_t kind = mov_kind(z, m);
     double *p = zoo_mov(z, m);
     double nx, ny, len, len2;
     if (kind == MKD_DRONE || kind == MKD_MINI) {   // entity_drone_zap.py:57-64, entity_mini_drone.py:60-67
@@ -712,7 +716,7 @@ DEV void mover_logical(const Zoo &z, int m, Nj &n, double &wall_normal) {
         if (pen_square(p[0], p[1], n.x, n.y, 9 + NINJA_RADIUS + 0.1, nx, ny, len, len2)) wall_normal += nx;
     } else if (kind == MKD_THWUMP) {   // entity_thwump.py:215-243
         if (valid_target(n.state) && pen_square(p[0], p[1], n.x, n.y, 9 + NINJA_RADIUS + 0.1, nx, ny, len, len2)) {
-            const uint32_t orient = (z.mov_meta[m] >> 3) & 7u;
+            const uint32_t orient = mov_orient(z, m);
             const bool horizontal = (orient == 0 || orient == 4);
             const int direction = (orient == 0 || orient == 2) ? 1 : -1;
             double px1, py1, px2, py2;
@@ -965,10 +969,9 @@ DEV void zoo_entities_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb,
     zoo_think_doors(lv, z, eb, n_ent);
     if (z.n_mov) {
         for (int m = r; m < z.n_mov; m += G)
-            if ((z.mov_meta[m] & 7u) == MKD_THWUMP) thwump_think(z, m, n);
+            if (mov_kind(z, m) == MKD_THWUMP) thwump_think(z, m, n);
         if (z.n_balls) {
-            int ball_first = 0;
-            while ((z.mov_meta[ball_first] & 7u) != MKD_BALL) ball_first++;
+            const int ball_first = z.ball_first;
             uint32_t ctr = zoo_head_w(z)[0];
             for (int k = 0; k < z.n_balls; k++) {
                 const int m = ball_first + k;
@@ -982,7 +985,7 @@ DEV void zoo_entities_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb,
             zoo_head_w(z)[0] = ctr;
         }
         zoo_pass<G>(z, r, [&](int m, int &newcell) {
-            return (z.mov_meta[m] & 7u) == MKD_SHOVE ? shove_think(z, m, newcell) : false;
+            return mov_kind(z, m) == MKD_SHOVE ? shove_think(z, m, newcell) : false;
         });
     }
 }
