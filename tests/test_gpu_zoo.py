@@ -358,3 +358,79 @@ def test_set_entity_pos_matches_reference(golden, oracle_mod):
         sw, door = mv["sw%d" % i], mv["door%d" % i]
         want = np.array([sw[0] / 1056.0, sw[1] / 600.0, door[0] / 1056.0, door[1] / 600.0], dtype=np.float32)
         assert np.allclose(ep_[k, 2:6], want, atol=1e-7), (i, ep_[k], want)
+
+
+def _fuzz_level(base, rng, keep_away=0.0):
+    """A real map's tiles + exit, with random zoo entities appended at empty tiles (map_loader.py:84-141 record layout:
+    5 values per entity, 9 for door types 6 / 8 with the switch at +6, +7)."""
+    m = np.asarray(base, dtype=np.float64).copy()
+    tiles = m[184:1150].reshape(23, 42)
+    empty = np.argwhere(tiles == 0)
+    if len(empty) < 8:
+        return m
+    extra = []
+    n_balls = 0
+    for _ in range(int(rng.integers(6, 28))):
+        t = int(rng.choice([1, 21, 2, 5, 6, 8, 10, 11, 14, 17, 20, 24, 25, 26, 28], p=None))
+        ry, rx = empty[rng.integers(len(empty))]
+        # pixel position inside the tile (tile (rx, ry) of the inner grid sits at world cell (rx + 1, ry + 1)), in map units of 6 px
+        x = (rx + 1) * 4 + int(rng.integers(0, 5))
+        y = (ry + 1) * 4 + int(rng.integers(0, 5))
+        if keep_away and abs(x * 6 - m[1231] * 6) + abs(y * 6 - m[1232] * 6) < keep_away:
+            continue    # long episodes: nothing lethal next to the spawn
+        orient = int(rng.integers(0, 8))
+        mode = int(rng.integers(0, 4))
+        if t in (14, 20, 26, 5, 6, 8):
+            orient = int(rng.choice([0, 2, 4, 6]))
+        if t in (6, 8):
+            sy, sx = empty[rng.integers(len(empty))]
+            extra += [t, x, y, orient, mode, 0, (sx + 1) * 4 + 2, (sy + 1) * 4 + 2, 0]
+        else:
+            extra += [t, x, y, orient, mode]
+        n_balls += t == 25
+    out = np.concatenate([m, np.array(extra, dtype=np.float64)])
+    out[1200] = n_balls
+    return out
+
+
+def test_zoo_fuzz_random_entities(oracle_mod):
+    """Random entity soups on real tile sets: every kind incl. the ones the recorded corpus barely has (regular doors, trap
+    doors, shove thwumps, diagonal launch pads / one-ways, all drone modes), GPU vs the oracle twin, bit for bit, through
+    episodes with auto-reset.  The oracle is pinned by the reference's replays for the kinds they contain; for the rest this
+    checks two independent implementations (C lists vs merged CSR walk) against each other."""
+    from nclone_amd.levels import curriculum0_levels, mine_levels
+
+    bases = curriculum0_levels()[0][::5] + mine_levels()[0][::6]
+    rng = np.random.default_rng(2024)
+    levels = [_fuzz_level(bases[k % len(bases)], rng, keep_away=(0.0 if k % 2 else 160.0)) for k in range(48)]
+    n = len(levels)
+    b = _batch(n, autoreset=True)
+    b.load_levels(levels)
+    b.assign_levels(np.arange(n))
+    steps = 150
+    acts = rng.integers(0, 6, size=(steps, n)).astype(np.uint8)
+    acts[:, ::4] = 0      # a quarter of the envs just stand at the spawn: long episodes for the entities to wander
+    d = torch.from_numpy(acts).cuda()
+    sims = []
+    for e in range(n):
+        o = oracle_mod.Oracle("mul")
+        o.load(levels[e])
+        sims.append(o)
+    episodes = 0
+    for s in range(steps):
+        b.step(d[s])
+        f, di = b.dump_state()
+        cs = b.entity_checksum()
+        fl = b.flags.cpu().numpy()
+        for e in range(n):
+            _, ofl = sims[e].env_step(int(acts[s, e]), 4)
+            assert bool(fl[e] & 3) == bool(ofl), (s, e, fl[e], ofl)
+            if ofl:
+                sims[e].reset()
+                episodes += 1
+            of, od = sims[e].core()
+            assert np.array_equal(f[e], of), (s, e, f[e], of)
+            assert np.array_equal(di[e, :22], od[:22]), (s, e)
+            assert np.array_equal(cs[e], sims[e].entity_checksum()), (s, e, cs[e] - sims[e].entity_checksum())
+    print("fuzz: %d levels x %d steps, %d episodes ended" % (n, steps, episodes))
+    assert episodes > 5
