@@ -12,8 +12,9 @@
  * platforms, zap and mini drones, bounce blocks, thwumps, boost pads, death balls, shove
  * thwumps) -- the remaining 26 bc_replays (5 886 ticks, per-tick entity checksums) and
  * 9 zoo rollouts (10 776 ticks) from tests/golden/make_golden_zoo.py: 130 of 130 replays.
- * Regular doors (type 5) occur in none of the reference's maps: restated from
- * entity_door_regular.py, parity unpinned for that one kind.
+ * plus 28 random "entity soup" levels run through the reference (make_golden_fuzz.py, 12 537 ticks:
+ * regular / trap doors, shove thwumps, every orientation and drone mode) and repositioned exit
+ * switches / doors (make_golden_moved.py).
  *
  * Where the reference writes `x**2` CPython calls libm pow(|x|, 2.0), which is NOT
  * always equal to x*x on glibc.  The default build uses

@@ -360,37 +360,7 @@ def test_set_entity_pos_matches_reference(golden, oracle_mod):
         assert np.allclose(ep_[k, 2:6], want, atol=1e-7), (i, ep_[k], want)
 
 
-def _fuzz_level(base, rng, keep_away=0.0):
-    """A real map's tiles + exit, with random zoo entities appended at empty tiles (map_loader.py:84-141 record layout:
-    5 values per entity, 9 for door types 6 / 8 with the switch at +6, +7)."""
-    m = np.asarray(base, dtype=np.float64).copy()
-    tiles = m[184:1150].reshape(23, 42)
-    empty = np.argwhere(tiles == 0)
-    if len(empty) < 8:
-        return m
-    extra = []
-    n_balls = 0
-    for _ in range(int(rng.integers(6, 28))):
-        t = int(rng.choice([1, 21, 2, 5, 6, 8, 10, 11, 14, 17, 20, 24, 25, 26, 28], p=None))
-        ry, rx = empty[rng.integers(len(empty))]
-        # pixel position inside the tile (tile (rx, ry) of the inner grid sits at world cell (rx + 1, ry + 1)), in map units of 6 px
-        x = (rx + 1) * 4 + int(rng.integers(0, 5))
-        y = (ry + 1) * 4 + int(rng.integers(0, 5))
-        if keep_away and abs(x * 6 - m[1231] * 6) + abs(y * 6 - m[1232] * 6) < keep_away:
-            continue    # long episodes: nothing lethal next to the spawn
-        orient = int(rng.integers(0, 8))
-        mode = int(rng.integers(0, 4))
-        if t in (14, 20, 26, 5, 6, 8):
-            orient = int(rng.choice([0, 2, 4, 6]))
-        if t in (6, 8):
-            sy, sx = empty[rng.integers(len(empty))]
-            extra += [t, x, y, orient, mode, 0, (sx + 1) * 4 + 2, (sy + 1) * 4 + 2, 0]
-        else:
-            extra += [t, x, y, orient, mode]
-        n_balls += t == 25
-    out = np.concatenate([m, np.array(extra, dtype=np.float64)])
-    out[1200] = n_balls
-    return out
+from tests.fuzz_levels import fuzz_level as _fuzz_level  # noqa: E402
 
 
 def test_zoo_fuzz_random_entities(oracle_mod):
@@ -434,3 +404,37 @@ def test_zoo_fuzz_random_entities(oracle_mod):
             assert np.array_equal(cs[e], sims[e].entity_checksum()), (s, e, cs[e] - sims[e].entity_checksum())
     print("fuzz: %d levels x %d steps, %d episodes ended" % (n, steps, episodes))
     assert episodes > 5
+
+
+def test_fuzz_levels_vs_reference_fixtures(golden):
+    """The 28 entity-soup levels the REFERENCE was run on (fuzz.npz): npp_step with auto-reset against its per-tick ninja
+    state, discrete state and entity checksum at every step boundary, and per-step frames / termination."""
+    z = golden.z("fuzz")
+    n = int(z["n"][0])
+    b = _batch(n, autoreset=True)
+    b.load_levels([z["m%d" % k] for k in range(n)])
+    b.assign_levels(np.arange(n))
+    steps = len(z["a0"])
+    acts = np.stack([z["a%d" % k] for k in range(n)], axis=1)
+    d = torch.from_numpy(acts).cuda()
+    rows = np.zeros(n, dtype=np.int64)
+    episodes = 0
+    for s in range(steps):
+        b.step(d[s], frame_skip=4)
+        flags = b.flags.cpu().numpy()
+        frames = b.frames.cpu().numpy().astype(np.int64)
+        f, di = b.dump_state()
+        cs = b.entity_checksum()
+        for k in range(n):
+            ex, term, frame = z["s%d" % k][s]
+            assert frames[k] == ex, (k, s, frames[k], ex)
+            assert (1 if flags[k] & 1 else (2 if flags[k] & 2 else 0)) == term, (k, s, flags[k], term)
+            rows[k] += ex
+            if not term:
+                ref = z["t%d" % k][rows[k] - 1]
+                assert np.abs(f[k, :4] - ref).max() <= POS_TOL, (k, s, f[k, :4], ref)
+                assert np.array_equal(_disc(di[k : k + 1])[0], z["d%d" % k][rows[k] - 1]), (k, s)
+                assert np.abs(cs[k] - z["e%d" % k][rows[k] - 1]).max() <= ENT_TOL, (k, s, cs[k] - z["e%d" % k][rows[k] - 1])
+            else:
+                episodes += 1
+    assert episodes > 100

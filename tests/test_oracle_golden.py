@@ -214,6 +214,38 @@ def test_oracle_repositioned_switch_and_door(golden, oracle_mod, variant):
         assert D[-1][0] == 8
 
 
+def test_oracle_fuzz_levels_vs_reference(golden, oracle_mod):
+    """28 random "entity soup" levels run through the reference (fuzz.npz, make_golden_fuzz.py): regular doors, trap doors,
+    shove thwumps, every orientation and drone mode -- kinds the recorded replays barely contain.  Bit for bit, every tick,
+    incl. the entity checksum and the resets."""
+    z = golden.z("fuzz")
+    ticks = 0
+    for k in range(int(z["n"][0])):
+        o = oracle_mod.Oracle("pow")
+        o.load(z["m%d" % k])
+        T, D, E, S = z["t%d" % k], z["d%d" % k], z["e%d" % k], z["s%d" % k]
+        row = 0
+        for s, a in enumerate(z["a%d" % k]):
+            h, j = oracle_mod.ACTIONS[a]
+            ex = fl = 0
+            for _ in range(4):
+                o.tick(h, j)
+                ex += 1
+                f, d = o.core()
+                assert np.array_equal(f[:4], T[row]), (k, s, row, f[:4], T[row])
+                assert np.array_equal(d[:20].clip(0, 255), D[row]), (k, s, row)
+                assert np.array_equal(o.entity_checksum(), E[row]), (k, s, row, o.entity_checksum() - E[row])
+                row += 1
+                if d[0] in (6, 7, 8):
+                    fl = 1 if d[0] == 8 else 2
+                    break
+            assert (ex, fl, o.frame) == tuple(S[s]), (k, s)
+            if fl:
+                o.reset()
+        ticks += row
+    assert ticks == 12537
+
+
 def test_oracle_spatial_context(golden, oracle_mod):
     """spatial_context rows from the reference's spatial_context.py (loaded by file, see make_golden.py)."""
     r = golden.z("rollouts")
