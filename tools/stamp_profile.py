@@ -31,7 +31,7 @@ def main():
     lib.npp_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int, C.c_int]
     n = 8192
     workload = os.environ.get("NPP_STAMP_WORKLOAD", "c0")
-    levels, _ = {"c0": level_sets.curriculum0_levels, "zoo": level_sets.zoo_levels, "mines": level_sets.mine_levels}[workload]()
+    levels, _ = {"c0": level_sets.curriculum0_levels, "zoo": level_sets.zoo_levels, "mines": level_sets.mine_levels, "doors": level_sets.door_levels}[workload]()
     print("workload", workload, len(levels), "levels")
     rng = np.random.default_rng(0)
     K, W = 100, 100
