@@ -18,7 +18,17 @@ from . import spaces
 from .engine import NppBatch
 
 ACTION_TABLE = [(0, 0), (-1, 0), (1, 0), (0, 1), (-1, 1), (1, 1)]  # base_environment.py:366-402
-DEATH_CAUSES = {0: None, 1: "mine", 2: "terminal_impact"}
+DEATH_CAUSES = {0: None, 1: "mine", 2: "terminal_impact", 3: None}   # 3: drone / thwump / death ball / crush: kill() without a cause
+MAX_TIME_IN_FRAMES = 10000   # gym_environment/constants.py:8-10
+
+
+def calculate_truncation_limit(surface_area, reachable_mine_count=0):
+    """Dynamic truncation limit of the reference (gym_environment/truncation_calculator.py:19-57):
+    clip((sqrt(surface_area) * 20 + mines * 75) * 25, 1200, MAX_TIME_IN_FRAMES).  `surface_area` (reachable graph nodes)
+    comes from the reference's reachability graph, which stays in the reference; pass the result to
+    NppBatch.set_truncation_limit / NppVecEnvironment(truncation_limit=...)."""
+    v = (np.sqrt(surface_area) * 20.0 + reachable_mine_count * 75.0) * 25
+    return int(np.clip(v, 1200, MAX_TIME_IN_FRAMES))
 
 
 def controls_to_input_byte(hor, jump):

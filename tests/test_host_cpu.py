@@ -124,6 +124,18 @@ def test_replay_format_v0_v1(golden):
     assert [decode_input_to_controls(b) for b in range(8)] == [(0, 0), (0, 1), (1, 0), (1, 1), (-1, 0), (-1, 1), (0, 0), (0, 1)]
 
 
+def test_truncation_limit_formula():
+    """gym_environment/truncation_calculator.py:19-57 evaluated by hand: (sqrt(A) * 20 + mines * 75) * 25 clipped to
+    [1200, 10000]."""
+    from nclone_amd.vec_env import calculate_truncation_limit
+
+    assert calculate_truncation_limit(1.0, 0) == 1200            # 500 -> floor
+    assert calculate_truncation_limit(36.0, 1) == 4875           # (120 + 75) * 25
+    assert calculate_truncation_limit(100.0, 0) == 5000
+    assert calculate_truncation_limit(400.0, 3) == 10000         # clipped to MAX_TIME_IN_FRAMES
+    assert calculate_truncation_limit(50.0, 0) == int(np.sqrt(50.0) * 20.0 * 25)
+
+
 def test_host_helpers():
     from nclone_amd import spaces
     from nclone_amd.distributed import shard_envs
