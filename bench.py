@@ -209,6 +209,28 @@ def main():
         for sb in subs:
             sb.close()
 
+    # secondary figure: the same K steps as launches of 50 steps each (npp_step_many): open-loop action sequences, as in
+    # batched checkpoint replay; wavefronts run through their steps without waiting for the slowest env of every step
+    many_rep = None
+    if world == 1 and not args.gather_obs and K >= 50:
+        mb = NppBatch(n, device=local_rank, autoreset=True)
+        mb.load_levels(levels)
+        mb.assign_levels((np.arange(n) // 64) % len(levels))
+        chunk = 50
+        mb.step_many(acts[:W])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done_steps = 0
+        for k0 in range(W, W + K - chunk + 1, chunk):
+            mb.step_many(acts[k0:k0 + chunk])
+            done_steps += chunk
+        torch.cuda.synchronize()
+        mdt = time.perf_counter() - t0
+        many_rep = {"steps_per_launch": chunk, "steps": done_steps, "value": n * done_steps / mdt, "unit": "env-steps/s",
+                    "note": "npp_step_many: open-loop action sequences (no observation between steps), per-step flags / "
+                            "rewards still written; not the headline metric"}
+        mb.close()
+
     if rank == 0:
         value = world * n * K / dt
         launch_us = dev_ms * 1e3 / K   # HIP events on the launch stream: average duration per npp_step launch
@@ -256,6 +278,8 @@ def main():
         }
         if async_rep is not None:
             line["async_subbatches"] = async_rep
+        if many_rep is not None:
+            line["open_loop_rollout"] = many_rep
         if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(levels)

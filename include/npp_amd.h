@@ -114,6 +114,14 @@ int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all);
  * truncation check (:613), observation (:627,680). */
 int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_step_out *out);
 
+/* Several Gymnasium steps in ONE launch, for action sequences that do not depend on the observations in between: batched
+ * checkpoint replay (the reference's ActionReplayer.replay_to_checkpoint, action_replayer.py, replays one env at a time),
+ * rollouts of a fixed plan.  d_actions: u8[n_steps][n_envs].  d_flags / d_reward / d_frames of `out` receive
+ * [n_steps][n_envs] values (one row per step); the observations are those after the last step; with auto-reset an env that
+ * terminates mid-sequence restarts on the spot (no terminal observation in this mode).  Wavefronts advance through their
+ * steps independently, so the launch costs the sum of average step times instead of the sum of worst-case step times. */
+int npp_step_many(npp_handle h, const uint8_t *d_actions, int n_steps, int frame_skip, const npp_step_out *out);
+
 /* NPlayHeadless.tick(h, j) (nplay_headless.py:322) for all envs, n_ticks times, driven by replay input
  * bytes d_inputs[n_ticks][N] (bit0 jump, bit1 right, bit2 left: replay/replay_executor.py:61-84).
  * No early stop, no truncation, no auto-reset: the caller polls state like tools/test_replay_playback.py. */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnpp_amd.so")
 SOURCES = ["npp_kernels.hip", "npp_render.hip", "npp_capi.cpp", "npp_level.cpp"]
-HEADERS = ["npp_internal.hpp", "npp_level.hpp", os.path.join("..", "..", "include", "npp_amd.h")]
+HEADERS = ["npp_internal.hpp", "npp_level.hpp", "npp_zoo.hpp", os.path.join("..", "..", "include", "npp_amd.h")]
 
 
 def needs_build():
@@ -25,18 +25,29 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile every translation unit in parallel (npp_kernels.hip four times, -DNPP_TU=0..3: one (ZOO, MANY) family of step
+    kernels each), then link."""
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [
-        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
-        "-I", os.path.join(HERE, "..", "include"), "-o", OUT,
-    ] + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+             "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    jobs = [("npp_kernels.hip", ["-DNPP_TU=%d" % k], "npp_kernels_tu%d.o" % k) for k in range(4)]
+    jobs += [("npp_render.hip", [], "npp_render.o"), ("npp_capi.cpp", [], "npp_capi.o"), ("npp_level.cpp", [], "npp_level.o")]
+    procs = []
+    for src, extra, obj in jobs:
+        cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [os.path.join(objdir, j[2]) for j in jobs])
     return OUT
 
 

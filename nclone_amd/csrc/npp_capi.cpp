@@ -465,6 +465,20 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
     return NPP_OK;
 }
 
+int npp_step_many(npp_handle h, const uint8_t *d_actions, int n_steps, int frame_skip, const npp_step_out *out) {
+    if (!h || !d_actions || frame_skip <= 0 || n_steps <= 0) return fail(h, NPP_ERR_INVALID, "npp_step_many: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_step_many: no levels loaded");
+    KernelArgs a = base_args(h);
+    a.inputs = d_actions;
+    a.n_ticks = frame_skip;
+    a.n_steps = n_steps;
+    a.mode = 0;
+    fill_out(a, out);
+    a.out.terminal_state = nullptr;   // pre-reset observations exist for single steps only
+    HIP_TRY(h, launch_step(a, h->stream));
+    return NPP_OK;
+}
+
 int npp_tick(npp_handle h, const uint8_t *d_inputs, int n_ticks) {
     if (!h || !d_inputs || n_ticks <= 0) return fail(h, NPP_ERR_INVALID, "npp_tick: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_tick: no levels loaded");

@@ -84,6 +84,7 @@ struct KernelArgs {
     const uint8_t *reset_mask;  // reset kernel only; NULL = all
     int n;
     int n_ticks;          // frame_skip (mode 0) or tick count (mode 1); 0 = observe only
+    int n_steps;          // mode 0: Gymnasium steps per launch (npp_step_many); 0 / 1 = one
     int mode;             // 0 gym step, 1 raw ticks
     int autoreset;
     int n_words_max;

@@ -1375,7 +1375,7 @@ DEV void block_store_rows(const uint32_t *stage, uint32_t *dst_block, int width,
 }
 
 // G lanes per env; EPW = 64 / G envs per wavefront; blockDim.x / 64 wavefronts per workgroup
-template <int G, bool LDS_LEVEL, bool ZOO>
+template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
 DEV void run(const KernelArgs &a, unsigned char *smem) {
     constexpr int EPW = WAVE / G;
     const int tid = threadIdx.x;
@@ -1477,53 +1477,67 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     uint32_t flags = 0;
     int executed = 0;
     float reward = 0.f;
-    const bool had_switch = lv.obs_switch >= 0 && ent_get(eb, lv.obs_switch) == 0;
-
-    {
-        // mode 0: NppEnvironment.step frame-skip loop (base_environment.py:524-609), action table :366-402; an env that
-        //         is already terminal (no auto-reset) is not stepped again until the caller resets it
-        // mode 1: NPlayHeadless.tick driven by replay bytes (replay/replay_executor.py:61-84), never stops early
-        const bool gym = a.mode == 0;
-        const int act = (gym && a.n_ticks > 0) ? a.inputs[e] : 0;
-        int hor = (act == 1 || act == 4) ? -1 : ((act == 2 || act == 5) ? 1 : 0);
-        int jump = act >= 3 ? 1 : 0;
-        bool live = valid && !(gym && (n.state == 8 || n.state == 6 || n.state == 7));
-        for (int t = 0; t < a.n_ticks; t++) {
-            if (!gym) {
-                const int b = a.inputs[(size_t)t * a.n + e];
-                const int l = (b >> 2) & 1, rr = (b >> 1) & 1;
-                hor = (l && rr) ? 0 : (l ? -1 : (rr ? 1 : 0));
-                jump = b & 1;
-            }
-            if (live) {
-                sim_tick<G, ZOO>(lv, z, r, n, eb, hor, jump, (int)H.n_ent STAMP_PASS);
-                executed++;
-                if (gym && (n.state == 8 || n.state == 6 || n.state == 7)) live = false;
-            }
-            if (!__any(live)) break;
-        }
-    }
-
-    STAMP(1);
-    const bool sw_now = lv.obs_switch >= 0 ? ent_get(eb, lv.obs_switch) == 0 : true;   // nplay_headless.py:566-576
-    if (n.state == 8) flags |= 1u;
-    if (n.state == 6 || n.state == 7) flags |= 2u;
-    if (sw_now) flags |= 4u;
-    if (n.cause == 1) flags |= 16u;
-    if (n.cause == 2) flags |= 32u;
-    bool done = (flags & 3u) != 0;
+    bool done = false;
     const bool stepping = a.mode == 0 && a.n_ticks > 0;
-    if (stepping && !done && n.frame >= limit) { flags |= 8u; done = true; }   // truncation_checker.py:46-77
-    // sparse terminal reward: completion 200, switch 100, death -30, scaled by 0.1 (reward_constants.py:71,115,148,212)
-    if (flags & 1u) reward += 20.f;
-    if (flags & 2u) reward -= 3.f;
-    if (sw_now && !had_switch && lv.obs_switch >= 0) reward += 10.f;
-
     const bool writer = valid && r == 0;
-    if (writer) {
-        if (a.out.flags) a.out.flags[env] = (uint8_t)flags;
-        if (a.out.reward) a.out.reward[env] = reward;
-        if (a.out.frames) a.out.frames[env] = (uint16_t)executed;
+    // npp_step_many: several Gymnasium steps in one launch (open-loop action sequences: checkpoint replay, rollouts of a
+    // fixed plan).  Wavefronts walk their steps independently, so nobody waits for the slowest env of every single step.
+    // (its own instantiation, MANY: the single-step kernels keep a constant trip count of one)
+    const int n_steps = MANY ? (a.n_steps > 1 ? a.n_steps : 1) : 1;
+#pragma nounroll
+    for (int sidx = 0; sidx < n_steps; sidx++) {
+        flags = 0; executed = 0; reward = 0.f;
+        const bool had_switch = lv.obs_switch >= 0 && ent_get(eb, lv.obs_switch) == 0;
+        {
+            // mode 0: NppEnvironment.step frame-skip loop (base_environment.py:524-609), action table :366-402; an env that
+            //         is already terminal (no auto-reset) is not stepped again until the caller resets it
+            // mode 1: NPlayHeadless.tick driven by replay bytes (replay/replay_executor.py:61-84), never stops early
+            const bool gym = a.mode == 0;
+            const int act = (gym && a.n_ticks > 0) ? a.inputs[(size_t)sidx * a.n + e] : 0;
+            int hor = (act == 1 || act == 4) ? -1 : ((act == 2 || act == 5) ? 1 : 0);
+            int jump = act >= 3 ? 1 : 0;
+            bool live = valid && !(gym && (n.state == 8 || n.state == 6 || n.state == 7));
+            for (int t = 0; t < a.n_ticks; t++) {
+                if (!gym) {
+                    const int b = a.inputs[(size_t)t * a.n + e];
+                    const int l = (b >> 2) & 1, rr = (b >> 1) & 1;
+                    hor = (l && rr) ? 0 : (l ? -1 : (rr ? 1 : 0));
+                    jump = b & 1;
+                }
+                if (live) {
+                    sim_tick<G, ZOO>(lv, z, r, n, eb, hor, jump, (int)H.n_ent STAMP_PASS);
+                    executed++;
+                    if (gym && (n.state == 8 || n.state == 6 || n.state == 7)) live = false;
+                }
+                if (!__any(live)) break;
+            }
+        }
+
+        STAMP(1);
+        const bool sw_now = lv.obs_switch >= 0 ? ent_get(eb, lv.obs_switch) == 0 : true;   // nplay_headless.py:566-576
+        if (n.state == 8) flags |= 1u;
+        if (n.state == 6 || n.state == 7) flags |= 2u;
+        if (sw_now) flags |= 4u;
+        if (n.cause == 1) flags |= 16u;
+        if (n.cause == 2) flags |= 32u;
+        done = (flags & 3u) != 0;
+        if (stepping && !done && n.frame >= limit) { flags |= 8u; done = true; }   // truncation_checker.py:46-77
+        // sparse terminal reward: completion 200, switch 100, death -30, scaled by 0.1 (reward_constants.py:71,115,148,212)
+        if (flags & 1u) reward += 20.f;
+        if (flags & 2u) reward -= 3.f;
+        if (sw_now && !had_switch && lv.obs_switch >= 0) reward += 10.f;
+
+        if (writer) {
+            const size_t o = (size_t)sidx * a.n + env;
+            if (a.out.flags) a.out.flags[o] = (uint8_t)flags;
+            if (a.out.reward) a.out.reward[o] = reward;
+            if (a.out.frames) a.out.frames[o] = (uint16_t)executed;
+        }
+        if (MANY && sidx + 1 < n_steps && a.autoreset && stepping && done) {   // intermediate steps reset on the spot
+            spawn_state(lv, n);
+            for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
+            if (ZOO && z.on) zoo_init_block(z, r, G, false);
+        }
     }
 
     const bool do_reset = a.autoreset && stepping && done;
@@ -1593,10 +1607,10 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 
 // LDS_LEVEL is chosen by the host: true when every workgroup's envs play one level that fits the LDS budget
 // (the host knows the env -> level assignment), false otherwise (tables are read through L1/L2).
-template <int G, bool LDS_LEVEL, bool ZOO>
+template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
 __global__ __launch_bounds__(256) void npp_step_kernel(KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    run<G, LDS_LEVEL, ZOO>(a, smem);
+    run<G, LDS_LEVEL, ZOO, MANY>(a, smem);
 }
 
 // Simulator.reset / fast_reset (nsim.py:62-140) for masked envs
@@ -1641,35 +1655,61 @@ __global__ __launch_bounds__(256) void npp_restore_kernel(KernelArgs a, const do
         for (int k = 0; k < a.zoo_words; k++) a.zoo[(size_t)env * a.zoo_words + k] = sz[(size_t)env * a.zoo_words + k];
 }
 
-template <int G>
+// This file is compiled four times (build_native.py: -DNPP_TU=0..3), each translation unit instantiating the step kernels
+// of one (ZOO, MANY) pair, so that the 56 instantiations build in parallel.  TU 0 also holds the small kernels.  The
+// diagnostic -DNPP_STAMPS build is a single translation unit with everything.
+#ifndef NPP_TU
+#define NPP_TU 0
+#endif
+
+template <int G, bool Z, bool M>
 hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
     const int wpb = a.waves_per_block;
     const int epb = (WAVE / G) * wpb;
     const int blocks = (a.n + epb - 1) / epb;
-    if (a.zoo_active) {   // zoo levels: LDS also holds the per-env zoo blocks
-        const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb, a.zoo_words);
-        if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
-        else hipLaunchKernelGGL((npp_step_kernel<G, false, true>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
-        return hipGetLastError();
-    }
-    const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb);
-    if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, false>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
-    else hipLaunchKernelGGL((npp_step_kernel<G, false, false>), dim3(blocks), dim3(WAVE * wpb), lds, s, a);
+    const dim3 grid(blocks), block(WAVE * wpb);
+    // zoo levels: LDS also holds the per-env zoo blocks
+    const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb, Z ? a.zoo_words : 0);
+    if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, Z, M>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((npp_step_kernel<G, false, Z, M>), grid, block, lds, s, a);
     return hipGetLastError();
+}
+
+template <bool Z, bool M>
+hipError_t launch_step_zm(const KernelArgs &a, hipStream_t s) {
+    switch (a.lanes_per_env) {
+        case 1: return launch_step_g<1, Z, M>(a, s);
+        case 2: return launch_step_g<2, Z, M>(a, s);
+        case 4: return launch_step_g<4, Z, M>(a, s);
+        case 8: return launch_step_g<8, Z, M>(a, s);
+        case 16: return launch_step_g<16, Z, M>(a, s);
+        case 32: return launch_step_g<32, Z, M>(a, s);
+        case 64: return launch_step_g<64, Z, M>(a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
 
+#if NPP_TU == 0
+#ifdef NPP_STAMPS
+hipError_t launch_step_tu0(const KernelArgs &a, hipStream_t s) { return launch_step_zm<false, false>(a, s); }
+hipError_t launch_step_tu1(const KernelArgs &a, hipStream_t s) { return launch_step_zm<true, false>(a, s); }
+hipError_t launch_step_tu2(const KernelArgs &a, hipStream_t s) { return launch_step_zm<false, true>(a, s); }
+hipError_t launch_step_tu3(const KernelArgs &a, hipStream_t s) { return launch_step_zm<true, true>(a, s); }
+#else
+hipError_t launch_step_tu0(const KernelArgs &a, hipStream_t s) { return launch_step_zm<false, false>(a, s); }
+hipError_t launch_step_tu1(const KernelArgs &a, hipStream_t s);
+hipError_t launch_step_tu2(const KernelArgs &a, hipStream_t s);
+hipError_t launch_step_tu3(const KernelArgs &a, hipStream_t s);
+#endif
+
 hipError_t launch_step(const KernelArgs &a, hipStream_t s) {
-    switch (a.lanes_per_env) {
-        case 1: return launch_step_g<1>(a, s);
-        case 2: return launch_step_g<2>(a, s);
-        case 4: return launch_step_g<4>(a, s);
-        case 8: return launch_step_g<8>(a, s);
-        case 16: return launch_step_g<16>(a, s);
-        case 32: return launch_step_g<32>(a, s);
-        case 64: return launch_step_g<64>(a, s);
-        default: return hipErrorInvalidValue;
+    switch ((a.zoo_active ? 1 : 0) | (a.n_steps > 1 ? 2 : 0)) {
+        case 0: return launch_step_tu0(a, s);
+        case 1: return launch_step_tu1(a, s);
+        case 2: return launch_step_tu2(a, s);
+        default: return launch_step_tu3(a, s);
     }
 }
 
@@ -1713,6 +1753,14 @@ extern "C" int npp_debug_stamps(unsigned long long *out, int n_waves, int reset)
     }
     return 0;
 }
+#endif
+
+#elif NPP_TU == 1
+hipError_t launch_step_tu1(const KernelArgs &a, hipStream_t s) { return launch_step_zm<true, false>(a, s); }
+#elif NPP_TU == 2
+hipError_t launch_step_tu2(const KernelArgs &a, hipStream_t s) { return launch_step_zm<false, true>(a, s); }
+#else
+hipError_t launch_step_tu3(const KernelArgs &a, hipStream_t s) { return launch_step_zm<true, true>(a, s); }
 #endif
 
 }  // namespace npp

@@ -128,6 +128,24 @@ class NppBatch:
         out = self._out if want_terminal else self._out_min
         nat.check(self.h, self.lib.npp_step(self.h, C.c_void_p(actions.data_ptr()), int(frame_skip), C.byref(out)))
 
+    def step_many(self, actions, frame_skip=4):
+        """actions: uint8 CUDA tensor [K, N].  K Gymnasium steps in one launch (open-loop sequences: checkpoint replay, fixed
+        plans).  Returns (flags u8 [K, N], reward f32 [K, N], frames i16 [K, N]); observations of the last step land in
+        self.game_state etc.; with auto-reset, envs that terminate mid-sequence restart on the spot."""
+        assert actions.dtype == torch.uint8 and actions.is_cuda and actions.dim() == 2 and actions.shape[1] == self.n
+        actions = actions.contiguous()
+        K = int(actions.shape[0])
+        flags = torch.zeros((K, self.n), dtype=torch.uint8, device=self.device)
+        reward = torch.zeros((K, self.n), dtype=torch.float32, device=self.device)
+        frames = torch.zeros((K, self.n), dtype=torch.int16, device=self.device)
+        out = nat.StepOut(self.game_state.data_ptr(), self.action_mask.data_ptr(), self.entity_pos.data_ptr(), flags.data_ptr(),
+                          reward.data_ptr(), frames.data_ptr(), None,
+                          self.spatial_context.data_ptr() if self.spatial_context is not None else None)
+        nat.check(self.h, self.lib.npp_step_many(self.h, C.c_void_p(actions.data_ptr()), K, int(frame_skip), C.byref(out)))
+        self._keep = actions
+        self.flags.copy_(flags[-1]); self.reward.copy_(reward[-1]); self.frames.copy_(frames[-1])
+        return flags, reward, frames
+
     def tick(self, inputs):
         """inputs: uint8 CUDA tensor [T, N] of replay input bytes (bit0 jump, bit1 right, bit2 left)."""
         assert inputs.dtype == torch.uint8 and inputs.is_cuda and inputs.dim() == 2 and inputs.shape[1] == self.n

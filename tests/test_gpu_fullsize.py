@@ -160,3 +160,41 @@ def test_checkpoint_snapshot_restore_and_action_replay():
     fa, ia = b.dump_state()
     assert np.array_equal(fa, f0) and np.array_equal(ia, i0)
     assert np.abs(fa[:, :2] - f0[:, :2]).max() < 0.01   # POSITION_VALIDATION_THRESHOLD (state_checkpoint.py)
+
+
+def test_step_many_equals_single_steps():
+    """npp_step_many (K steps per launch) against K calls of npp_step on plain, mine and zoo levels: same final state, same
+    per-step flags / rewards / frames, same final observation; with auto-reset and a truncation limit in play."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import curriculum0_levels, mine_levels, zoo_levels
+
+    levels = curriculum0_levels()[0][:6] + mine_levels()[0][:4] + zoo_levels()[0][:4]
+    n = 64 * len(levels)
+    lvl = np.arange(n) // 64
+    rng = np.random.default_rng(77)
+    K = 60
+    acts = torch.from_numpy(rng.integers(0, 6, size=(K, n)).astype(np.uint8)).cuda()
+    ref = NppBatch(n, autoreset=True)
+    ref.load_levels(levels)
+    ref.assign_levels(lvl)
+    ref.set_truncation_limit(150)
+    fl, rw, fr = [], [], []
+    for s in range(K):
+        ref.step(acts[s], want_terminal=False)
+        fl.append(ref.flags.clone()); rw.append(ref.reward.clone()); fr.append(ref.frames.clone())
+    f_ref, i_ref = ref.dump_state()
+    c_ref = ref.entity_checksum()
+    gs_ref = ref.game_state.cpu().numpy()
+    b = NppBatch(n, autoreset=True)
+    b.load_levels(levels)
+    b.assign_levels(lvl)
+    b.set_truncation_limit(150)
+    flags, reward, frames = b.step_many(acts[:25])
+    f2, r2, fr2 = b.step_many(acts[25:])
+    f, i = b.dump_state()
+    assert np.array_equal(f, f_ref) and np.array_equal(i, i_ref) and np.array_equal(b.entity_checksum(), c_ref)
+    assert np.array_equal(b.game_state.cpu().numpy(), gs_ref)
+    assert torch.equal(torch.cat([flags, f2]), torch.stack(fl))
+    assert torch.equal(torch.cat([reward, r2]), torch.stack(rw))
+    assert torch.equal(torch.cat([frames, fr2]), torch.stack(fr))
+    assert int((torch.stack(fl) & 11).ne(0).sum()) > 50      # episodes did end (and restart) inside the sequences
