@@ -280,7 +280,7 @@ def main():
             line["async_subbatches"] = async_rep
         if many_rep is not None:
             line["open_loop_rollout"] = many_rep
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(levels)
             except Exception as e:  # the baseline is a reported figure, never a dependency of the GPU number
