@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--async-streams", type=int, default=4,
                     help="also time the same K steps with the envs split into this many independent sub-batches on "
                          "separate HIP streams (reported as async_subbatches, never as value); 0 = skip")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the "
+                                                      "multi-rank path on one GPU together with --device)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal on a one-GPU box)")
     ap.add_argument("--workload", default="c0", choices=["c0", "mines", "doors", "zoo"],
                     help="c0 = config 2 (the headline metric); the others are secondary level sets")
     args = ap.parse_args()
@@ -107,6 +110,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device is not None:
+        local_rank = args.device
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
@@ -114,7 +119,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
@@ -161,7 +169,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     done_frac = float((b.flags & 3).ne(0).float().mean().item())
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
