@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--async-streams", type=int, default=4,
                     help="also time the same K steps with the envs split into this many independent sub-batches on "
                          "separate HIP streams (reported as async_subbatches, never as value); 0 = skip")
+    ap.add_argument("--open-loop-chunk", type=int, default=50,
+                    help="also time the K steps as npp_step_many launches of this many steps (open_loop_rollout; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the "
                                                       "multi-rank path on one GPU together with --device)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal on a one-GPU box)")
@@ -220,11 +222,11 @@ def main():
     # secondary figure: the same K steps as launches of 50 steps each (npp_step_many): open-loop action sequences, as in
     # batched checkpoint replay; wavefronts run through their steps without waiting for the slowest env of every step
     many_rep = None
-    if world == 1 and not args.gather_obs and K >= 50:
+    if world == 1 and not args.gather_obs and args.open_loop_chunk > 0 and K >= args.open_loop_chunk:
         mb = NppBatch(n, device=local_rank, autoreset=True)
         mb.load_levels(levels)
         mb.assign_levels((np.arange(n) // 64) % len(levels))
-        chunk = 50
+        chunk = args.open_loop_chunk
         mb.step_many(acts[:W])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
