@@ -664,7 +664,9 @@ DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += d
 
 #define NPP_DEPEN_STEP(io, m, BREAK)                                                                   \
     {                                                                                                  \
-        if ((m).idx == 0x7fffffff) BREAK; /* result == 0 */                                            \
+        /* the reference leaves the loop at three places (ninja.py:307, 326, 331); nothing is modified \
+         * before the last of them, so the three tests are folded into one exit */                     \
+        const bool none = (m).idx == 0x7fffffff; /* result == 0 */                                     \
         const int result = ((m).idx & 1) ? -1 : 1;                                                     \
         double ddx = (io).x - (m).a;                                                                   \
         double ddy = (io).y - (m).b;                                                                   \
@@ -674,10 +676,10 @@ DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += d
             if ((io).x == 49.153536108584795) ddx = 0x1p-47;                                           \
         }                                                                                              \
         double dist_sq = ddx * ddx + ddy * ddy;                                                        \
-        if (dist_sq < 1e-16) BREAK;                                                                    \
-        double dist = sqrt_inrange(dist_sq); /* 1e-16 <= dist_sq */                                    \
+        const bool tiny = dist_sq < 1e-16;                                                             \
+        double dist = sqrt_inrange(dist_sq); /* garbage when tiny: the exit below does not look at it */ \
         double depen_len = NINJA_RADIUS - dist * result;                                               \
-        if (depen_len < 0.0000001) BREAK;                                                              \
+        if (none | tiny | (depen_len < 0.0000001)) BREAK;                                              \
         (io).applied = 1;                                                                              \
         double inv_dist = rcp_inrange(dist);                                                           \
         double norm_dx = ddx * inv_dist, norm_dy = ddy * inv_dist;                                     \
@@ -786,6 +788,13 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
     crush_in(io, cr);
     STAMP(9);   // sweep + gather setup
     if (fast) {
+        // Loop-invariant, wavefront-uniform shortcuts (scalar branches instead of exec-mask regions inside the chain):
+        // does any gathered candidate of this wavefront describe an arc / sit in a slot beyond the first?
+        bool arc_here = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) arc_here |= ((gp >> k) & 1u) && (cd.s[k] & 1u);
+        const bool wave_arcs = __any(arc_here);
+        const bool wave_more = __any((gp >> 1) != 0);
         for (int it = 0; it < 32; it++) {
 #ifdef NPP_STAMPS
             st.acc[10] += 1;   // iteration count (register fast path)
@@ -796,13 +805,13 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
             const double qx0 = io.x - NINJA_RADIUS, qy0 = io.y - NINJA_RADIUS, qx1 = io.x + NINJA_RADIUS, qy1 = io.y + NINJA_RADIUS;
 #pragma unroll
             for (int k = 0; k < K; k++)
-                if ((gp >> k) & 1u) {
+                if (k == 0 || (wave_more && ((gp >> k) & 1u))) {   // slot 0 is evaluated unconditionally (masked by gp below)
                     double bx0 = __builtin_fmin(cd.x1[k], cd.x2[k]), bx1 = __builtin_fmax(cd.x1[k], cd.x2[k]);
                     double by0 = __builtin_fmin(cd.y1[k], cd.y2[k]), by1 = __builtin_fmax(cd.y1[k], cd.y2[k]);
-                    bool in = !((bx1 < qx0) | (bx0 > qx1) | (by1 < qy0) | (by0 > qy1));
+                    bool in = ((gp >> k) & 1u) & !((bx1 < qx0) | (bx0 > qx1) | (by1 < qy0) | (by0 > qy1));
                     double a, b;
                     bool back = cand_closest_lin(cd, k, io.x, io.y, a, b);
-                    if (in & ((cd.s[k] & 1u) != 0)) back = cand_closest_arc(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], io.x, io.y, a, b);
+                    if (wave_arcs && (in & ((cd.s[k] & 1u) != 0))) back = cand_closest_arc(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], io.x, io.y, a, b);
                     double distance_sq = sq(io.x - a) + sq(io.y - b);
                     double key = back ? distance_sq : distance_sq - 0.1;
                     bool take = in & (key < m.key);
