@@ -667,7 +667,7 @@ DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += d
         /* the reference leaves the loop at three places (ninja.py:307, 326, 331); nothing is modified \
          * before the last of them, so the three tests are folded into one exit */                     \
         const bool none = (m).idx == 0x7fffffff; /* result == 0 */                                     \
-        const int result = ((m).idx & 1) ? -1 : 1;                                                     \
+        const bool back_facing = ((m).idx & 1) != 0; /* result = -1 (physics.py:179) */                \
         double ddx = (io).x - (m).a;                                                                   \
         double ddy = (io).y - (m).b;                                                                   \
         if (dabs(ddx) <= 0.0000001) { /* band-aid constants of the reference (ninja.py:313-318) */     \
@@ -678,7 +678,7 @@ DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += d
         double dist_sq = ddx * ddx + ddy * ddy;                                                        \
         const bool tiny = dist_sq < 1e-16;                                                             \
         double dist = sqrt_inrange(dist_sq); /* garbage when tiny: the exit below does not look at it */ \
-        double depen_len = NINJA_RADIUS - dist * result;                                               \
+        double depen_len = NINJA_RADIUS - (back_facing ? -dist : dist); /* dist * result, exactly */   \
         if (none | tiny | (depen_len < 0.0000001)) BREAK;                                              \
         (io).applied = 1;                                                                              \
         double inv_dist = rcp_inrange(dist);                                                           \
@@ -814,9 +814,16 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
                     if (wave_arcs && (in & ((cd.s[k] & 1u) != 0))) back = cand_closest_arc(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], io.x, io.y, a, b);
                     double distance_sq = sq(io.x - a) + sq(io.y - b);
                     double key = back ? distance_sq : distance_sq - 0.1;
-                    bool take = in & (key < m.key);
-                    m.key = take ? key : m.key; m.a = take ? a : m.a; m.b = take ? b : m.b;
-                    m.idx = take ? (((k * G + r) << 8) | (r << 1) | (back ? 1 : 0)) : m.idx;
+                    const int code = ((k * G + r) << 8) | (r << 1) | (back ? 1 : 0);
+                    if (k == 0) {
+                        // first slot: nothing to compare with yet; a lane that is not `in` keeps key = inf / idx = none and
+                        // can never be the winner, so its point need not be masked
+                        m.key = in ? key : m.key; m.idx = in ? code : m.idx; m.a = a; m.b = b;
+                    } else {
+                        bool take = in & (key < m.key);
+                        m.key = take ? key : m.key; m.a = take ? a : m.a; m.b = take ? b : m.b;
+                        m.idx = take ? code : m.idx;
+                    }
                 }
             group_argmin<G>(m);
             NPP_DEPEN_STEP(io, m, break)
