@@ -198,3 +198,50 @@ def test_step_many_equals_single_steps():
     assert torch.equal(torch.cat([reward, r2]), torch.stack(rw))
     assert torch.equal(torch.cat([frames, fr2]), torch.stack(fr))
     assert int((torch.stack(fl) & 11).ne(0).sum()) > 50      # episodes did end (and restart) inside the sequences
+
+
+def test_long_horizon_soak(oracle_mod):
+    """2 600 steps (10 400 ticks: past the 10 000-frame truncation) of 2 048 envs on plain, mine and zoo levels with auto-reset;
+    every 43rd env is replayed on the oracle twin (same truncation rule) and must end in the same bits -- thousands of
+    episodes, list-order counters in the tens of thousands, saturating frame counters."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import curriculum0_levels, mine_levels, zoo_levels
+
+    levels = curriculum0_levels()[0][24:34] + mine_levels()[0][:8] + zoo_levels()[0][:14]
+    n = 64 * len(levels)
+    lvl = np.arange(n) // 64
+    rng = np.random.default_rng(123)
+    steps = 2600
+    acts = rng.integers(0, 6, size=(steps, n)).astype(np.uint8)
+    acts[:, 5::64] = 0                      # one idle env per level: only truncation ends its episodes
+    d = torch.from_numpy(acts).cuda()
+    b = NppBatch(n, autoreset=True)
+    b.load_levels(levels)
+    b.assign_levels(lvl)
+    ended = torch.zeros(n, dtype=torch.int64, device="cuda")
+    trunc = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for k0 in range(0, steps, 100):
+        flags, _, _ = b.step_many(d[k0 : k0 + 100])
+        ended += (flags & 11).ne(0).sum(dim=0)
+        trunc += (flags & 8).ne(0).sum(dim=0)
+    f, i = b.dump_state()
+    cs = b.entity_checksum()
+    ended = ended.cpu().numpy()
+    assert int(trunc.sum()) >= len(levels)          # the idle envs were truncated at frame 10 000
+    checked = 0
+    for e in list(range(3, n, 43)) + list(range(5, n, 256)):
+        o = oracle_mod.Oracle("mul")
+        o.load(levels[lvl[e]])
+        eps = 0
+        for s in range(steps):
+            _, fl = o.env_step(int(acts[s, e]), 4)
+            if fl or o.frame >= 10000:
+                o.reset()
+                eps += 1
+        of, od = o.core()
+        assert eps == ended[e], (e, eps, ended[e])
+        assert np.array_equal(f[e], of), (e, lvl[e], f[e], of)
+        assert np.array_equal(i[e, :22].clip(0, 65535), od[:22].clip(0, 65535)), (e, lvl[e], i[e, :22], od[:22])
+        assert np.array_equal(cs[e], o.entity_checksum()), (e, lvl[e])
+        checked += 1
+    print("soak: %d envs x %d steps, %d episodes, %d truncations, %d envs checked" % (n, steps, int(ended.sum()), int(trunc.sum()), checked))
