@@ -79,8 +79,10 @@ void plan_geometry(npp_handle h) {
     int g = h->lanes_per_env;
     if (const char *ev = std::getenv("NPP_LANES_PER_ENV")) g = std::atoi(ev);
     if (g <= 0) {
+        // measured on MI355X (tools/sweep_geometry.py, tools/big_batch_probe.py): 16 lanes per env up to 16 384 envs, 8 at
+        // 32 768, 4 from 65 536 on (95.8 M env-steps/s there; 2 lanes per env is 2.5x slower at any size)
         g = 16;
-        while (g > 1 && (long long)h->n * g / 64 > 2048) g >>= 1;
+        while (g > 4 && (long long)h->n * g / 64 > 4096) g >>= 1;
     }
     int gg = 1;
     while (gg * 2 <= g && gg < 64) gg *= 2;
