@@ -31,6 +31,17 @@ def test_header_symbols_exported(native):
     assert sorted(native.EXPORTS) == declared
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/npp_amd.h must compile as C99 (no C++-isms, no torch / HIP types)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "npp_amd.h"\nint main(void) { npp_handle h = 0; (void)h; return NPP_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+
+
 def test_level_compiler_matches_reference_tables(native, golden):
     from nclone_amd.engine import compile_level_entities, compile_level_segments
 
