@@ -145,6 +145,10 @@ int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y);
  * switch position (its segment has no `p1`), reproduced.  No runnable reference for this one: parity by source reading. */
 int npp_switch_states(npp_handle h, float *d_out);
 
+/* The whole gray frame of envs [env0, env0 + count): what NPlayHeadless.render() returns in grayscale mode
+ * (nplay_headless.py:144-156, nsim_renderer.py:71-134).  d_out: u8[count][600][1056]. */
+int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out);
+
 /* global_view (observation_processor.py:304-328): the (600 x 1056) gray frame through cv2.resize(frame, (100, 176), INTER_AREA).
  * The reference's RENDERED_VIEW_WIDTH / HEIGHT are swapped (gym_environment/constants.py:18-19), so the frame is squashed to
  * 176 rows x 100 columns; reproduced as is (area-weighted mean of the source pixels).  d_out: u8[n_envs][176][100]. */

@@ -24,7 +24,7 @@ EXPORTS = [
     "npp_assign_levels", "npp_reset", "npp_set_truncation_limit", "npp_step", "npp_tick", "npp_observe",
     "npp_render_player_frame", "npp_dump_state", "npp_dump_entities", "npp_dump_level_segments",
     "npp_compile_level_segments", "npp_compile_level_entities", "npp_num_envs", "npp_num_levels",
-    "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many",
+    "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many", "npp_render_frame",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
     L.npp_switch_states.argtypes = [H, C.c_void_p]
     L.npp_set_entity_pos.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double]
     L.npp_step_many.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.POINTER(StepOut)]
+    L.npp_render_frame.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
     L.npp_snapshot.argtypes = [H]
     L.npp_restore.argtypes = [H, C.POINTER(C.c_uint8)]
     L.npp_num_envs.argtypes = [H]

@@ -548,6 +548,14 @@ int npp_switch_states(npp_handle h, float *d_out) {
     return NPP_OK;
 }
 
+int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out) {
+    if (!h || !d_out || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_render_frame: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_frame: no levels loaded");
+    KernelArgs a = base_args(h);
+    HIP_TRY(h, launch_full_frame(a, env0, count, d_out, h->stream));
+    return NPP_OK;
+}
+
 int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_global_view: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_global_view: no levels loaded");

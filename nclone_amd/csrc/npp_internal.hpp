@@ -135,6 +135,7 @@ hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint
                           const float *src_sc, const double *src_zoo, hipStream_t s);
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
 hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
+hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *d_out, hipStream_t s);
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
 
 }  // namespace npp

@@ -353,6 +353,23 @@ __global__ __launch_bounds__(128) void npp_global_view_kernel(KernelArgs a, uint
     out[((size_t)env * GV_ROWS + r) * GV_COLS + c] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
 }
 
+// The whole gray canvas of one env range (NPlayHeadless.render() in grayscale mode: nsim_renderer.py:71-134, array of shape
+// (600, 1056, 1), nplay_headless.py:144-156).  One workgroup per (env, canvas row).
+__global__ __launch_bounds__(256) void npp_full_frame_kernel(KernelArgs a, int env0, uint8_t *out) {
+    __shared__ Draw s_draw[GV_DRAW];
+    __shared__ int s_n;
+    const int e = blockIdx.x / 600, y = blockIdx.x - e * 600;
+    const int env = env0 + e;
+    if (env >= a.n) return;
+    const LevelHdr &H = a.hdr[a.env_level[env]];
+    const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
+    if (threadIdx.x == 0) s_n = build_draw_list(a, H, env, px, py, -16.f, y - 16.f, 1056.f + 16.f, y + 1 + 16.f, s_draw, GV_DRAW);
+    __syncthreads();
+    const uint8_t *tiles = a.blob + H.off_tiles;
+    uint8_t *row = out + ((size_t)e * 600 + y) * 1056;
+    for (int x = threadIdx.x; x < 1056; x += blockDim.x) row[x] = (uint8_t)canvas_pixel(s_draw, s_n, tiles, x, y);
+}
+
 // switch_states (gym_environment/npp_environment.py:1782-1847): up to MAX_LOCKED_DOORS = 5 locked doors x [switch x, switch y,
 // door x, door y, collected].  _extract_locked_door_positions looks for `segment.p1`, which GridSegmentLinear does not have
 // (entities.py: x1, y1, x2, y2), so the "door" position falls back to the entity's xpos / ypos -- the switch position
@@ -378,6 +395,11 @@ __global__ __launch_bounds__(256) void npp_switch_states_kernel(KernelArgs a, fl
 }
 
 }  // namespace
+
+hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(npp_full_frame_kernel, dim3(count * 600), dim3(256), 0, s, a, env0, d_out);
+    return hipGetLastError();
+}
 
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s) {
     hipLaunchKernelGGL(npp_switch_states_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a, d_out);

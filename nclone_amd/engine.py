@@ -173,6 +173,12 @@ class NppBatch:
         nat.check(self.h, self.lib.npp_switch_states(self.h, C.c_void_p(out.data_ptr())))
         return out
 
+    def render_frame(self, env0=0, count=1):
+        """uint8 CUDA tensor [count, 600, 1056, 1]: the whole gray frame (the reference's render() array) of some envs."""
+        out = torch.zeros((count, 600, 1056, 1), dtype=torch.uint8, device=self.device)
+        nat.check(self.h, self.lib.npp_render_frame(self.h, int(env0), int(count), C.c_void_p(out.data_ptr())))
+        return out
+
     def render_global_view(self, out):
         """out: uint8 CUDA tensor [N, 176, 100] (or [N, 176, 100, 1]): the reference's global_view of every env."""
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 176 * 100 and out.is_contiguous()

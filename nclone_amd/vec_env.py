@@ -270,6 +270,10 @@ class NPlayHeadless:
         p = self._b.entity_pos[0].cpu().numpy().astype(np.float64)
         return float(p[4] * 1056.0), float(p[5] * 600.0)
 
+    def render(self):
+        """The gray frame, numpy uint8 (600, 1056, 1), as the reference's render() returns it (nplay_headless.py:144-156)."""
+        return self._b.render_frame(0, 1)[0].cpu().numpy()
+
     def _entities(self):
         """(compiled rows [kind, x, y, cx, cy, init], live 2-bit states) of the loaded level, map order."""
         from .engine import compile_level_entities

@@ -128,6 +128,28 @@ def test_global_view(golden, oracle_mod):
         assert ref.std() > 10       # a real picture, not a constant
 
 
+def test_full_frame_consistent_with_player_frame_and_reference_raster(golden, oracle_mod):
+    """render(): the whole 600 x 1056 frame.  Its crop around the player must BE the player_frame (same pixel function), and
+    a band of it matches the numpy rasteriser under the usual tolerance."""
+    from tests.raster_ref import render_canvas
+
+    b, sims, f = _zoo_batch_and_oracles(golden, oracle_mod, True, n_steps=40)
+    pf = torch.zeros((b.n, 84, 84), dtype=torch.uint8, device="cuda")
+    b.render_player_frame(pf)
+    pf = pf.cpu().numpy()
+    for e in (0, 3, 5):
+        full = b.render_frame(e, 1)[0, :, :, 0].cpu().numpy()
+        px, py = f[e, 0], f[e, 1]
+        r0, r1, c0, c1 = max(0, int(py - 42)), min(600, int(py + 42)), max(0, int(px - 42)), min(1056, int(px + 42))
+        h, w = r1 - r0, c1 - c0
+        top, left = (84 - h) // 2, (84 - w) // 2
+        assert np.array_equal(pf[e][top:top + h, left:left + w], full[r0:r1, c0:c1]), e
+        y0 = max(0, min(600 - 60, int(py) - 30))
+        ref, edge = render_canvas(sims[e].tiles(), sims[e].draw_list(), px, py, 0, y0, 1056, 60)
+        dlt = np.abs(full[y0:y0 + 60].astype(np.int64) - ref.astype(np.int64))
+        assert len(np.argwhere((dlt > 0) & ~edge)) == 0 and dlt.max(initial=0) <= 64 and dlt.mean() < 2.0, e
+
+
 def test_vec_env_surface(golden):
     """Gymnasium-shaped classes: keys, shapes, dtypes, unbatched adapter, facade replay to a win."""
     from nclone_amd.replay import CompactReplay, validate_replays
