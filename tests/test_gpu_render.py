@@ -239,3 +239,26 @@ def test_switch_states_and_facade_entity_views(golden):
     m1, m21 = hp.get_mine_entities()
     assert all(m.state == 0 for m in m1) and all(m.state == 1 for m in m21)
     hp.exit()
+
+
+def test_vec_env_on_zoo_levels_with_all_observations(golden):
+    """The Gymnasium-shaped vector env on levels full of moving entities with every observation switched on: shapes, dtypes,
+    a few hundred steps with auto-reset, frames that actually show the entities (not a constant picture)."""
+    from nclone_amd.levels import zoo_levels
+    from nclone_amd.vec_env import NppVecEnvironment
+
+    levels, _ = zoo_levels()
+    v = NppVecEnvironment(levels[:6], 48, level_ids=np.arange(48) % 6, enable_visual_observations=True, enable_spatial_context=True,
+                          enable_switch_states=True, output="numpy")
+    obs, _ = v.reset()
+    assert set(obs) == {"game_state", "action_mask", "entity_positions", "spatial_context", "switch_states", "player_frame", "global_view"}
+    rng = np.random.default_rng(2)
+    ended = 0
+    for s in range(120):
+        obs, rew, term, trunc, info = v.step(rng.integers(0, 6, size=48).astype(np.uint8))
+        ended += int(term.sum() + trunc.sum())
+    assert obs["global_view"].shape == (48, 176, 100, 1) and obs["global_view"].std() > 5
+    assert obs["spatial_context"].shape == (48, 112) and obs["switch_states"].shape == (48, 25)
+    assert np.isfinite(obs["game_state"]).all() and np.abs(obs["game_state"]).max() <= 1.0 + 1e-6
+    assert ended > 0 and set(np.unique(info["death_cause_code"])) <= {0, 1, 2}
+    v.close()
