@@ -67,6 +67,20 @@ def door_levels():
     return out, tags
 
 
+def c3_mixed_levels():
+    """The 512-level "curriculum 3, mixed map set" of BASELINE.json config 4: the 128 curriculum-0
+    levels + the 64 mine levels + 320 generated levels of the reference's `simpler` and `simple` categories restricted to
+    entity types {1, 3, 4, 21} (tests/golden/make_golden_c3.py; map_generation/generator_configs.py:732-760)."""
+    out, tags = curriculum0_levels()
+    m, t = mine_levels()
+    out, tags = out + m, tags + t
+    g = np.load(os.path.join(_GOLDEN, "levels_c3.npz"))
+    for k, n in enumerate(_names(g)):
+        out.append(g["L%d" % k])
+        tags.append(n)
+    return out, tags
+
+
 def zoo_levels():
     """The 26 bc_replays maps with the entity zoo (doors, launch / boost pads, one-ways, drones, bounce blocks, thwumps,
     death balls, shove thwumps): SURVEY.md 8(f) row 2."""

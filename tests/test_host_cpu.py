@@ -65,6 +65,26 @@ def test_level_compiler_matches_reference_tables(native, golden):
         assert ref == got, k
 
 
+def test_level_compiler_c3_mixed_set(native, golden):
+    """Config 4's 320 extra levels: entity tables of all, ordered segment dumps of every 4th (reference dumps)."""
+    from nclone_amd.engine import compile_level_entities, compile_level_segments
+    from nclone_amd.levels import c3_mixed_levels
+
+    g = golden.z("levels_c3")
+    kind = {1: 1, 21: 1, 2: 2, 3: 3, 4: 4, 6: 6}
+    n = len(golden.names("levels_c3"))
+    for k in range(n):
+        m = g["L%d" % k]
+        ref = sorted((kind[int(t)], x, y, cx, cy) for _, t, x, y, cx, cy, _, _ in g["ent%d" % k])
+        got = sorted((int(kk), x, y, cx, cy) for kk, x, y, cx, cy, _ in compile_level_entities(m))
+        assert ref == got, k
+        if "csr%d" % k in g.files:
+            rows, uns = compile_level_segments(m)
+            assert uns == 0 and np.array_equal(rows, g["c" + bytes(g["csr%d" % k]).decode()]), k
+    levels, tags = c3_mixed_levels()
+    assert len(levels) == 512 and len(set(tags)) == 512
+
+
 def test_level_compiler_zoo_tables_match_oracle(native, golden, oracle_mod):
     """Grid edges (what drones / thwumps test) and the mover table of the 26 zoo maps against the oracle's own build of
     them (the oracle is pinned by the reference's replays, where a wrong edge sends a drone the wrong way)."""

@@ -261,3 +261,39 @@ def test_oracle_spatial_context(golden, oracle_mod):
             if fl:
                 o.reset()
                 assert np.array_equal(o.spatial_context(), SC[s + 1]), (names[i], s)
+
+
+def test_oracle_c3_mixed_rollouts_and_tables(golden, oracle_mod):
+    """Config 4's extra 320 levels (categories `simpler` / `simple`, tests/golden/make_golden_c3.py): the reference's
+    rollouts on every 20th level bit for bit, entity tables of all of them, ordered segment dumps of every 4th."""
+    g = golden.z("levels_c3")
+    names = golden.names("levels_c3")
+    assert len(names) == 320
+    for k in range(len(names)):
+        o = oracle_mod.Oracle("pow")
+        assert o.load(g["L%d" % k]) == 0, names[k]
+        assert np.array_equal(o.dump_entities()[:, :6], g["ent%d" % k][:, :6]), names[k]
+        if "csr%d" % k in g.files:
+            assert np.array_equal(o.dump_csr(), g["c" + bytes(g["csr%d" % k]).decode()]), names[k]
+    ticks = 0
+    for r in range(int(g["n_rollouts"][0])):
+        k = int(g["rl%d" % r][0])
+        for variant in ("pow", "mul"):
+            o = oracle_mod.Oracle(variant)
+            assert o.load(g["L%d" % k]) == 0
+            T, D, S, G, K = g["rt%d" % r], g["rd%d" % r], g["rs%d" % r], g["rg%d" % r], g["rk%d" % r]
+            row = 0
+            for s, a in enumerate(g["ra%d" % r]):
+                ex, fl = o.env_step(int(a), 4)
+                f, d = o.core()
+                row += ex
+                assert (ex, fl, o.frame) == tuple(S[s]), (names[k], s)
+                assert np.array_equal(f[:4], T[row - 1]), (names[k], s, variant)
+                assert np.array_equal(d[:20].clip(0, 255), D[row - 1]), (names[k], s)
+                if variant == "pow":
+                    assert np.array_equal(o.ninja_state().astype(np.float32), G[s]), (names[k], s)
+                    assert o.action_mask() == K[s]
+                if fl:
+                    o.reset()
+            ticks += row
+    assert ticks == 2 * 19173
