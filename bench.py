@@ -1,22 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/s of the batched N++ stepper on MI355X (BASELINE.json metric, config 2).
+"""bench.py -- env-steps/s of the batched N++ stepper on MI355X (BASELINE.json metric; default = config 2).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one npp_step launch: every environment executes one Gymnasium step = frame_skip (4) physics ticks
 (early stop on win/death), truncation check, observation (game_state f32[41], action_mask i8[6],
-entity_positions f32[6], flags, reward, frames), in-kernel auto-reset.  Inputs (actions for all K+W steps)
-are resident in HBM before the timed region.  Workload: 8192 envs per GPU on 128 "curriculum 0" levels
-(exit+switch only) x 64 envs, actions iid uniform {0..5} from numpy default_rng(rank).
-Weak scaling: each rank (one process per GPU) steps its own 8192 envs; there is no data-path collective
-(--gather-obs adds the RCCL all_gather of config 4 for inspection; it is off for the headline metric).
+entity_positions f32[6], flags, reward, frames), in-kernel auto-reset.  Inputs (actions for every step) are resident
+in HBM before the timed region.
 
+Workloads:
+  c0       config 2 (headline): 8192 envs/GPU on 128 exit+switch levels x 64 envs, uniform random actions
+  mines    config 3 level set; with --player-frame the 84x84 raster of every env is rendered EVERY step inside the
+           timed region (npp_render_player_frame) and a second roofline is reported for the render kernel
+  c3mixed  config 4: the 512-level mixed set, 8192 envs/GPU (65 536 on 8 GPUs); --gather-obs adds the RCCL
+           all_gather of the packed observation block (game_state + entity_positions + reward + frames +
+           action_mask + flags) and the line reports the rate with and without it
+  doors    config 5 level set (physics + game_state; the reachability observation has its own benchmark line)
+  zoo      the 26 entity-zoo maps
+
+Before --warmup is honoured a fixed pre-roll of PREROLL_STEPS launches runs (reported as preroll_steps): episodes
+desynchronise and clocks ramp, so the figure does not depend on the caller's warm-up.  Every launch of the timed region
+is bracketed by HIP events on the launch stream: mean / p50 / p95 / max are reported, together with the levels that own
+the slowest 5 % of the launches (the env with the most depenetration iterations in that launch, npp_step_out.d_work).
+
+Weak scaling: each rank (one process per GPU) steps its own envs; there is no data-path collective unless --gather-obs.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,23 +42,26 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 8192
 FRAME_SKIP = 4
+PREROLL_STEPS = 300
 # algorithmic HBM bytes per env-step for the game_state-only observation
 # (state read 160 + state write 160 + action 1 + outputs 201)
 ALGO_BYTES_PER_ENV_STEP = 522
+# player_frame: 7056 B written + ~0.2 KB of state / level tables read per env
+ALGO_BYTES_PER_FRAME = 7056 + 200
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def committed_traffic():
-    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
-    gfx950 x2 correction on FETCH_SIZE) of this same command; tools/profile_round.sh collects them and
-    tools/summarize_profiles.py writes profiles/<round>_summary.json.  bench.py cannot run PMC passes on itself, so
-    it reports the newest committed figure (or null)."""
+def committed_traffic(kind="step"):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs) of this same
+    command; tools/profile_round.sh collects them and tools/summarize_profiles.py writes profiles/<round>_summary.json.
+    bench.py cannot run PMC passes on itself, so it reports the newest committed figure (or null)."""
     import glob
 
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
         try:
-            t = json.load(open(f)).get("traffic", {}).get("hbm_bytes_per_launch")
+            j = json.load(open(f))
+            t = j.get("traffic" if kind == "step" else "render_traffic", {}).get("hbm_bytes_per_launch")
             if t:
                 best = (float(t), os.path.basename(f))
         except Exception:
@@ -67,7 +84,6 @@ def cpu_baseline(levels, seconds_target=12.0):
         o.load(levels[(e * 7) % len(levels)])
         sims.append(o)
     rng = np.random.default_rng(12345)
-    # calibrate
     a = rng.integers(0, 6, size=(50, n_envs)).astype(np.uint8)
     t0 = time.perf_counter()
     om.run_batch(sims, a, FRAME_SKIP, 10000, threads)
@@ -88,13 +104,17 @@ def cpu_baseline(levels, seconds_target=12.0):
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--gather-obs", action="store_true", help="RCCL all_gather of game_state each step (config 4)")
+    ap.add_argument("--preroll", type=int, default=PREROLL_STEPS, help="fixed untimed launches before --warmup")
+    ap.add_argument("--gather-obs", action="store_true",
+                    help="also time the steps with the RCCL all_gather of the packed observation block (config 4)")
+    ap.add_argument("--player-frame", action="store_true",
+                    help="render the 84x84 player_frame of every env each step inside the timed region (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-streams", type=int, default=4,
                     help="also time the same K steps with the envs split into this many independent sub-batches on "
@@ -104,9 +124,49 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the "
                                                       "multi-rank path on one GPU together with --device)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal on a one-GPU box)")
-    ap.add_argument("--workload", default="c0", choices=["c0", "mines", "doors", "zoo"],
-                    help="c0 = config 2 (the headline metric); the others are secondary level sets")
-    args = ap.parse_args()
+    ap.add_argument("--workload", default="c0", choices=["c0", "mines", "doors", "zoo", "c3mixed"],
+                    help="c0 = config 2 (the headline metric); see the module docstring")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks itself")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's line.
+    The parent never touches torch.cuda / HIP (and never execs): each child initialises its own GPU."""
+    import socket
+
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+def percentiles(us):
+    a = np.sort(np.asarray(us, dtype=np.float64))
+    return {"mean": float(a.mean()), "p50": float(a[len(a) // 2]), "p95": float(a[min(len(a) - 1, int(0.95 * len(a)))]),
+            "max": float(a[-1]), "min": float(a[0])}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
 
@@ -128,110 +188,153 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     from nclone_amd.engine import NppBatch
     from nclone_amd import levels as level_sets
 
     levels, tags = {"c0": level_sets.curriculum0_levels, "mines": level_sets.mine_levels, "doors": level_sets.door_levels,
-                    "zoo": level_sets.zoo_levels}[args.workload]()
+                    "zoo": level_sets.zoo_levels, "c3mixed": level_sets.c3_mixed_levels}[args.workload]()
     n = args.envs_per_gpu
-    K, W = args.steps, args.warmup
-    b = NppBatch(n, device=local_rank, autoreset=True)
+    K, W, P = args.steps, args.warmup, args.preroll
+    outputs = ["work"] + (["player_frame"] if args.player_frame else [])
+    b = NppBatch(n, device=local_rank, autoreset=True, outputs=outputs)
     b.load_levels(levels)
-    # 64 consecutive envs (one wavefront / workgroup) per level, levels repeated round-robin
-    b.assign_levels((np.arange(n) // 64) % len(levels))
-    rng = np.random.default_rng(rank)
-    acts = torch.from_numpy(rng.integers(0, 6, size=(K + W, n)).astype(np.uint8)).cuda()
-    gathered = None
-    if args.gather_obs and dist is not None:
-        gathered = torch.empty((world * n, 41), dtype=torch.float32, device="cuda")
+    # 64 consecutive envs (one wavefront / workgroup) per level, levels repeated round-robin; with more ranks than one the
+    # global env index decides, so that 8 x 8192 envs cover all 512 levels of the mixed set twice
+    env_level = ((np.arange(n) + rank * n) // 64) % len(levels)
+    b.assign_levels(env_level)
+    rng = np.random.default_rng(rank + (2 if args.workload == "c3mixed" else 0))
+    total = P + W + K
+    acts = torch.from_numpy(rng.integers(0, 6, size=(total, n)).astype(np.uint8)).cuda()
+    work = torch.zeros((K, n), dtype=torch.int16, device="cuda")
+    stream = b.stream
 
-    def one(k):
-        b.step(acts[k], FRAME_SKIP, want_terminal=False)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, b.game_state)
+    def one(k, work_row=None):
+        b.step(acts[k], FRAME_SKIP, want_terminal=False, work_out=work_row)
+        if args.player_frame:
+            b.render_player_frame()
 
-    for k in range(W):
+    def timed(k0, gather=None):
+        """K launches from step index k0 on, bracketed by barrier + synchronize; per-launch HIP events on the launch stream."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+        mids = [torch.cuda.Event(enable_timing=True) for _ in range(K)] if args.player_frame else None
+        barrier()
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for k in range(K):
+            b.step(acts[k0 + k], FRAME_SKIP, want_terminal=False, work_out=work[k])
+            if mids is not None:
+                mids[k].record(stream)
+                b.render_player_frame()
+            if gather is not None:
+                gather()
+            evs[k + 1].record(stream)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        if mids is None:
+            step_us = [evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
+            render_us = None
+        else:
+            step_us = [evs[k].elapsed_time(mids[k]) * 1e3 for k in range(K)]
+            render_us = [mids[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
+        return dt, step_us, render_us
+
+    for k in range(P + W):
         one(k)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(W, W + K):
-        one(k)
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dt, step_us, render_us = timed(P + W)
     done_frac = float((b.flags & 3).ne(0).float().mean().item())
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    # secondary figure: the same envs as S independent sub-batches, each stepped K times on its own HIP stream with no
-    # cross-stream synchronisation until the end (an asynchronous / double-buffered vector env).  A synchronous step lasts
-    # as long as its slowest env's serial fp64 chain; independent sub-batches let other envs' work fill that tail.
+    # which levels own the slow launches: the env with the most depenetration iterations in each of the slowest 5 %
+    lt = np.asarray(step_us)
+    slow = np.argsort(lt)[-max(1, K // 20):]
+    wk = work[torch.from_numpy(np.sort(slow)).cuda()].cpu().numpy().astype(np.int64) & 0xffff
+    owners = env_level[np.argmax(wk, axis=1)]
+    ids, cnt = np.unique(owners, return_counts=True)
+    top = np.argsort(-cnt)[:6]
+    stragglers = {"launches": int(len(slow)), "iterations_max_env_mean": float(wk.max(axis=1).mean()),
+                  "iterations_all_envs_mean": float(wk.mean()),
+                  "levels": [{"level_id": int(ids[i]), "tag": tags[int(ids[i])], "launches": int(cnt[i])} for i in top]}
+
+    gather_rep = None
+    if args.gather_obs and dist is not None:
+        packed = b.out.packed()
+        if args.backend == "nccl":
+            gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device="cuda")
+
+            def gather():
+                dist.all_gather_into_tensor(gathered, packed)
+        else:   # gloo rehearsal: host tensors
+            gathered = torch.empty(world * packed.numel(), dtype=torch.uint8)
+            host = torch.empty(packed.numel(), dtype=torch.uint8)
+
+            def gather():
+                host.copy_(packed)
+                dist.all_gather_into_tensor(gathered, host)
+        for k in range(P, P + W):
+            one(k)
+            gather()
+        gdt, _, _ = timed(P + W, gather)
+        parts = b.out.split_packed(gathered, world)
+        ok = bool(torch.equal(parts["game_state"][rank].to(b.game_state.device), b.game_state))
+        gather_rep = {"value": world * n * K / gdt, "unit": "env-steps/s", "ms_per_step": gdt * 1e3 / K,
+                      "bytes_per_rank_per_step": int(packed.numel()), "collective": "all_gather_into_tensor (1 per step)",
+                      "own_shard_roundtrip_ok": ok,
+                      "fields": "game_state f32[41], entity_positions f32[6], reward f32, frames i16, action_mask i8[6], flags u8"}
+
+    # secondary figure: the asynchronous vector env (nclone_amd.async_env.NppAsyncVecEnvironment's engine): the same envs as S
+    # independent sub-batches, each stepped on its own HIP stream with no cross-stream synchronisation until the end.  A
+    # synchronous step lasts as long as its slowest env's serial fp64 chain; independent sub-batches fill that tail.
     async_rep = None
     S = args.async_streams
-    if S > 1 and world == 1 and n % (S * 64) == 0 and not args.gather_obs:   # single-GPU runs only: a secondary figure
-        sub = n // S
-        streams = [torch.cuda.Stream() for _ in range(S)]
-        subs = []
-        for k in range(S):
-            with torch.cuda.stream(streams[k]):
-                sb = NppBatch(sub, device=local_rank, autoreset=True, stream=streams[k])
-                sb.load_levels(levels)
-                sb.assign_levels(((np.arange(sub) + k * sub) // 64) % len(levels))
-                subs.append(sb)
-        torch.cuda.synchronize()
-        views = [acts[:, k * sub:(k + 1) * sub].contiguous() for k in range(S)]
+    if S > 1 and world == 1 and n % (S * 64) == 0 and not args.gather_obs and not args.player_frame:
+        from nclone_amd.async_env import AsyncBatches
 
-        def run_async(k0, k1):
-            for t in range(k0, k1):
-                for k in range(S):
-                    subs[k].step(views[k][t], FRAME_SKIP, want_terminal=False)
-
-        run_async(0, W)
+        ab = AsyncBatches(n, S, device=local_rank, autoreset=True)
+        ab.load_levels(levels)
+        ab.assign_levels(env_level)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        views = [acts[:, k * (n // S):(k + 1) * (n // S)].contiguous() for k in range(S)]
+        for t in range(P + W):
+            ab.step_async([v[t] for v in views], FRAME_SKIP)
+        ab.wait()
         t0 = time.perf_counter()
-        run_async(W, W + K)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        for t in range(P + W, total):
+            ab.step_async([v[t] for v in views], FRAME_SKIP)
+        ab.wait()
         adt = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([adt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            adt = float(tt.item())
-        async_rep = {"streams": S, "envs_per_stream": sub, "value": world * n * K / adt, "unit": "env-steps/s",
+        async_rep = {"streams": S, "envs_per_stream": n // S, "value": n * K / adt, "unit": "env-steps/s",
                      "ms_per_step_all_streams": adt * 1e3 / K,
                      "note": "same envs, levels and actions as `value`, stepped as independent sub-batches on separate HIP "
-                             "streams (no barrier between sub-batches); not the headline metric"}
-        for sb in subs:
-            sb.close()
+                             "streams (NppAsyncVecEnvironment); not the headline metric"}
+        ab.close()
 
     # secondary figure: the same K steps as launches of 50 steps each (npp_step_many): open-loop action sequences, as in
     # batched checkpoint replay; wavefronts run through their steps without waiting for the slowest env of every step
     many_rep = None
-    if world == 1 and not args.gather_obs and args.open_loop_chunk > 0 and K >= args.open_loop_chunk:
+    if world == 1 and not args.gather_obs and not args.player_frame and args.open_loop_chunk > 0 and K >= args.open_loop_chunk:
         mb = NppBatch(n, device=local_rank, autoreset=True)
         mb.load_levels(levels)
-        mb.assign_levels((np.arange(n) // 64) % len(levels))
+        mb.assign_levels(env_level)
         chunk = args.open_loop_chunk
-        mb.step_many(acts[:W])
+        mb.step_many(acts[:P + W])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         done_steps = 0
-        for k0 in range(W, W + K - chunk + 1, chunk):
+        for k0 in range(P + W, total - chunk + 1, chunk):
             mb.step_many(acts[k0:k0 + chunk])
             done_steps += chunk
         torch.cuda.synchronize()
@@ -243,8 +346,21 @@ def main():
 
     if rank == 0:
         value = world * n * K / dt
-        launch_us = dev_ms * 1e3 / K   # HIP events on the launch stream: average duration per npp_step launch
+        pl = percentiles(step_us)
+        launch_us = pl["mean"]   # HIP events on the launch stream: average duration per npp_step launch
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
+        desc = {
+            "c0": "config 2: %d envs/GPU, curriculum_level=0 (exit+switch only: 78 bc_replays maps + maze:tiny/hills:simple "
+                  "seeds 100001-100025 = %d levels x 64 envs), game_state+action_mask+entity_positions obs",
+            "mines": "config 3: %d envs/GPU, curriculum_level=2 (mines: 20 bc_replays maps + 44 generated corridor levels = %d "
+                     "levels x 64 envs)" + (", player_frame 84x84 rendered every step" if args.player_frame else ", raster off"),
+            "c3mixed": "config 4: %d envs/GPU (x n_gpus), curriculum_level=3 mixed map set (%d levels: c0 + mines + 320 generated "
+                       "simpler/simple levels) x 64 envs" + (", RCCL gather of the packed obs reported beside" if args.gather_obs else ""),
+            "doors": "config 5 level set: %d envs/GPU, curriculum_level=4 (locked doors / switches, %d levels x 64 envs), "
+                     "game_state obs (reachability: see bench_reachability)",
+            "zoo": "secondary level set 'zoo': %d envs/GPU on the %d entity-zoo maps x 64 envs",
+        }[args.workload] % (n, len(levels))
+        tr = committed_traffic("step") or (None, None)
         line = {
             "metric": "env-steps/sec (whole node) at N parallel envs",
             "value": value,
@@ -259,26 +375,25 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": ("config 2: %d envs/GPU, curriculum_level=0 (exit+switch only: 78 bc_replays maps + "
-                             "maze:tiny/hills:simple seeds 100001-100025 = %d levels x 64 envs), game_state+"
-                             "action_mask+entity_positions obs, frame_skip 4, uniform random actions, auto-reset"
-                             % (n, len(levels))) if args.workload == "c0" else
-                            ("secondary level set '%s': %d envs/GPU on %d levels x 64 envs, same observation and action "
-                             "distribution as config 2" % (args.workload, n, len(levels))),
+                "workload": desc + ", frame_skip 4, uniform random actions, auto-reset",
                 "envs_per_gpu": n,
                 "frame_skip": FRAME_SKIP,
                 "ticks_per_s": value * FRAME_SKIP,
-                "gather_obs": bool(gathered is not None),
+                "preroll_steps": P,
+                "player_frame": bool(args.player_frame),
+                "gather_obs": bool(gather_rep is not None),
                 "terminated_frac_last_step": done_frac,
             },
+            "launch_us": pl,
+            "stragglers": stragglers,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (committed_traffic() or (None, None))[0],
-                "traffic_source": (committed_traffic() or (None, None))[1],
+                "traffic": tr[0],
+                "traffic_source": tr[1],
                 "kernel": "npp_step_kernel",
                 "avg_launch_us": launch_us,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
@@ -286,6 +401,18 @@ def main():
                         "the HBM fraction is tiny by construction (SURVEY.md 8(d))",
             },
         }
+        if render_us is not None:
+            pr = percentiles(render_us)
+            ach = ALGO_BYTES_PER_FRAME * n / (pr["mean"] * 1e-6) / 1e9
+            rt = committed_traffic("render") or (None, None)
+            line["roofline_render"] = {
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": rt[0], "traffic_source": rt[1], "kernel": "npp_render_kernel", "avg_launch_us": pr["mean"],
+                "launch_us": pr, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * n,
+                "note": "7056 B written + ~0.2 KB read per env; parity of the raster is unpinned (no cairo/cv2 reference frame)",
+            }
+        if gather_rep is not None:
+            line["with_obs_gather"] = gather_rep
         if async_rep is not None:
             line["async_subbatches"] = async_rep
         if many_rep is not None:

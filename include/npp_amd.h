@@ -44,8 +44,16 @@ enum {
                                              (vector-env semantics; obs returned is the reset obs) */
     NPP_FLAG_ALLOW_UNSUPPORTED = 1u << 1, /* load levels with unsupported entity types, ignoring
                                              those entities (they are skipped, never simulated) */
-    NPP_FLAG_FRAME_CENTERED = 1u << 2     /* player_frame cropped around (x, y) as intended; default (0) reproduces
+    NPP_FLAG_FRAME_CENTERED = 1u << 2,    /* player_frame cropped around (x, y) as intended; default (0) reproduces
                                              the reference's axis-swapped crop (observation_processor.py:219-231) */
+    NPP_FLAG_FAST_RESET = 1u << 3         /* every reset after the first one of a level assignment has the semantics of
+                                             Simulator.fast_reset (nsim.py:78-140), which NppEnvironment.reset uses for
+                                             same-level resets (npp_environment.py:541-557): entities are reset in place,
+                                             so (a) the per-cell entity lists are rebuilt in entity_dic order (type key,
+                                             then creation order) instead of map order, and (b) entities whose class has
+                                             no reset_state() (drones, thwumps, bounce blocks, death balls, shove thwumps,
+                                             regular doors, boost pads) keep position and state, only `active` is set.
+                                             Default (0): every reset is Simulator.reset (nsim.py:62-76). */
 };
 
 /* out_flags bits written by npp_step */
@@ -81,6 +89,11 @@ typedef struct {
     float *d_spatial_context; /* [N,112] f32: 8x8 local tile categories + 8 nearest mines x 6 features
                                  (gym_environment/spatial_context.py:113-176,309-508 as called from
                                  npp_environment.py:2318-2360, incl. its >= 12 px position cache) */
+    double *d_positions;      /* [N,6]  f64: player_x, player_y, switch_x, switch_y, exit_door_x, exit_door_y in pixels:
+                                 the pass-through scalars of the raw observation (base_environment.py _get_observation ->
+                                 observation_processor.py:374-399), unrounded */
+    uint16_t *d_work;         /* [N]    u16: depenetration iterations this env ran in this step (collide_vs_tiles,
+                                 ninja.py:303-364) -- a profiling aid: the launch lasts as long as its busiest env */
 } npp_step_out;
 
 /* Simulator()+NPlayHeadless() for n_envs environments on GPU device_id. */
@@ -103,8 +116,13 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
  * means envs 0..n-1.  The listed envs are reset (Simulator.reset, nsim.py:62). */
 int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level_ids, int n);
 
-/* Simulator.reset / fast_reset (nsim.py:62-140) for the envs whose mask byte is non-zero (NULL = all). */
+/* Reset the envs whose mask byte is non-zero (NULL = all).  Without NPP_FLAG_FAST_RESET: Simulator.reset (nsim.py:62-76).
+ * With it: Simulator.reset for an env's first reset after npp_load_levels / npp_assign_levels, Simulator.fast_reset
+ * (nsim.py:78-140) afterwards -- the choice NppEnvironment.reset makes (npp_environment.py:541-557). */
 int npp_reset(npp_handle h, const uint8_t *env_mask);
+/* The same with an explicit choice: mode 0 = as npp_reset, 1 = Simulator.reset, 2 = Simulator.fast_reset
+ * (NPlayHeadless.reset / fast_reset, nplay_headless.py). */
+int npp_reset_ex(npp_handle h, const uint8_t *env_mask, int mode);
 
 /* Truncation limit in frames (truncation_checker.py:21-29); limits == NULL sets `all` for every env. */
 int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all);
@@ -199,6 +217,11 @@ int npp_restore(npp_handle h, const uint8_t *env_mask);
  * Results are bit-identical for every geometry; only speed changes. */
 int npp_set_launch_geometry(npp_handle h, int lanes_per_env, int waves_per_block);
 int npp_get_launch_geometry(npp_handle h, int *lanes_per_env, int *waves_per_block);
+
+/* Host-only (no GPU, no handle): the per-env "zoo block" (doors' edge counters + moving entities) a level SET needs.
+ * The block is sized over ALL levels of the set -- the reset kernel initialises the doors / movers of every level, not
+ * only of those with moving entities -- and npp_load_levels refuses a plan that does not cover one of its levels. */
+int npp_plan_zoo_block(const double *blob, const int64_t *offsets, int n_levels, int *doors, int *movers, int *words);
 
 int npp_num_envs(npp_handle h);
 int npp_num_levels(npp_handle h);

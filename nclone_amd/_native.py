@@ -14,6 +14,7 @@ NPP_OK = 0
 FLAG_AUTORESET = 1
 FLAG_ALLOW_UNSUPPORTED = 2
 FLAG_FRAME_CENTERED = 4
+FLAG_FAST_RESET = 8
 F_WON, F_DEAD, F_SWITCH, F_TRUNCATED, F_CAUSE_MINE, F_CAUSE_IMPACT = 1, 2, 4, 8, 16, 32
 GAME_STATE_DIM = 41
 DUMP_F64 = 12
@@ -24,7 +25,7 @@ EXPORTS = [
     "npp_assign_levels", "npp_reset", "npp_set_truncation_limit", "npp_step", "npp_tick", "npp_observe",
     "npp_render_player_frame", "npp_dump_state", "npp_dump_entities", "npp_dump_level_segments",
     "npp_compile_level_segments", "npp_compile_level_entities", "npp_num_envs", "npp_num_levels",
-    "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many", "npp_render_frame",
+    "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many", "npp_render_frame", "npp_plan_zoo_block", "npp_reset_ex",
 ]
 
 
@@ -38,6 +39,8 @@ class StepOut(C.Structure):
         ("d_frames", C.c_void_p),
         ("d_terminal_state", C.c_void_p),
         ("d_spatial_context", C.c_void_p),
+        ("d_positions", C.c_void_p),
+        ("d_work", C.c_void_p),
     ]
 
 
@@ -73,6 +76,7 @@ def lib():
     L.npp_load_levels.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.npp_assign_levels.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
     L.npp_reset.argtypes = [H, C.POINTER(C.c_uint8)]
+    L.npp_reset_ex.argtypes = [H, C.POINTER(C.c_uint8), C.c_int]
     L.npp_set_truncation_limit.argtypes = [H, C.POINTER(C.c_int32), C.c_int32]
     L.npp_step.argtypes = [H, C.c_void_p, C.c_int, C.POINTER(StepOut)]
     L.npp_tick.argtypes = [H, C.c_void_p, C.c_int]
@@ -94,6 +98,7 @@ def lib():
     L.npp_set_entity_pos.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double]
     L.npp_step_many.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.POINTER(StepOut)]
     L.npp_render_frame.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
+    L.npp_plan_zoo_block.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.npp_snapshot.argtypes = [H]
     L.npp_restore.argtypes = [H, C.POINTER(C.c_uint8)]
     L.npp_num_envs.argtypes = [H]

@@ -24,16 +24,18 @@ def needs_build():
     return False
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None, extra_flags=()):
     """Compile every translation unit in parallel (npp_kernels.hip four times, -DNPP_TU=0..3: one (ZOO, MANY) family of step
-    kernels each), then link."""
-    if not force and not needs_build():
+    kernels each), then link.  `out` / `extra_flags` build a variant elsewhere (tools/ab_bench.py A/B runs)."""
+    if out is None and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "_obj")
+    objdir = os.path.join(HERE, "_obj") if out is None else out + "_obj"
+    out = OUT if out is None else out
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
              "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
+    flags += list(extra_flags)
     if verbose:
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
     jobs = [("npp_kernels.hip", ["-DNPP_TU=%d" % k], "npp_kernels_tu%d.o" % k) for k in range(4)]
@@ -47,10 +49,13 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [os.path.join(objdir, j[2]) for j in jobs])
-    return OUT
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [os.path.join(objdir, j[2]) for j in jobs])
+    return out
 
 
 if __name__ == "__main__":
-    build(force=True, verbose="-v" in sys.argv)
-    print(OUT)
+    # python -m nclone_amd.build_native [-v] [--out PATH] [-- extra hipcc flags]
+    args = sys.argv[1:]
+    extra = args[args.index("--") + 1:] if "--" in args else []
+    out = args[args.index("--out") + 1] if "--out" in args else None
+    print(build(force=True, verbose="-v" in args, out=out, extra_flags=extra))

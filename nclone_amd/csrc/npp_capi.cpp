@@ -25,6 +25,7 @@ struct npp_handle_s {
     double *d_zoo = nullptr;   // per-env zoo blocks (always allocated with the levels; at least the 8-word head)
     std::vector<uint8_t> ovr;  // per env: ZOO_OVR_* flags set through npp_set_entity_pos
     int n_ovr = 0;
+    std::vector<uint8_t> s_ovr;   // the same at npp_snapshot (the zoo block's head words 3..7 travel with the snapshot)
     double *s_zoo = nullptr;
     int zoo_words = 0, zoo_doors = 0, zoo_movers = 0;
     int zoo_active = 0;        // some env is assigned a level with zoo entities
@@ -71,6 +72,34 @@ int fail(npp_handle h, int code, const std::string &msg) {
     } while (0)
 
 uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+// Every entry point that launches, copies or allocates runs with the HANDLE's device current and puts the caller's device
+// back afterwards: a caller whose current device differs (another handle, another framework) must neither receive our
+// launch on its GPU nor find its own current device changed.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ON_DEVICE(h)                                                                                          \
+    DeviceGuard _dg((h)->device);                                                                             \
+    if (_dg.err != hipSuccess) return fail(h, NPP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dg.err))
+
+// The per-env zoo block must hold the doors and movers of EVERY level of the set: the reset kernel writes n_zdoor door
+// words and n_mov mover records for whatever level an env plays, zoo level or not (a locked door has an edge counter too).
+void zoo_block_plan(const std::vector<CompiledLevel> &lv, int &doors, int &movers) {
+    doors = 0; movers = 0;
+    for (const CompiledLevel &L : lv) {
+        doors = std::max(doors, (int)(L.door_tab.size() / 2));
+        movers = std::max(movers, (int)L.mov_meta.size());
+    }
+}
 
 // Launch geometry (DESIGN.md "lanes per environment"): G lanes cooperate on one env.  The chip has 256 CUs x 4 SIMDs;
 // the path is a latency-bound fp64 dependency chain, so the grid is sized to put about two wavefronts on every SIMD
@@ -137,6 +166,7 @@ KernelArgs base_args(npp_handle h) {
     a.blob = h->d_blob;
     a.n = h->n;
     a.autoreset = (h->flags & NPP_FLAG_AUTORESET) ? 1 : 0;
+    a.fast_reset = (h->flags & NPP_FLAG_FAST_RESET) ? 1 : 0;   // in-kernel auto-resets
     a.n_words_max = h->n_words_max;
     a.lds_hot_cap = h->lds_hot_cap;
     a.lanes_per_env = h->geo_g;
@@ -160,16 +190,19 @@ void fill_out(KernelArgs &a, const npp_step_out *o) {
     a.out.frames = o->d_frames;
     a.out.terminal_state = o->d_terminal_state;
     a.out.spatial_context = o->d_spatial_context;
+    a.out.positions = o->d_positions;
+    a.out.work = o->d_work;
 }
 
 // `fresh` = the entities are created for the first time since the level was assigned (the state a replay starts from);
 // any later reset is a Simulator.reset(), after which Entity.index no longer starts at 0 (see ZOO_HEAD in npp_internal.hpp)
-int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh) {
+int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh, int fast = 0) {
     if (!h) return NPP_ERR_INVALID;
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reset: no levels loaded");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     a.reset_fresh = fresh;
+    a.fast_reset = fresh ? 0 : fast;
     if (env_mask) {
         HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
         a.reset_mask = h->d_mask;
@@ -192,7 +225,8 @@ int npp_create(int n_envs, int device_id, unsigned flags, npp_handle *out) {
     if (e != hipSuccess || count == 0)
         return fail(nullptr, NPP_ERR_HIP, "npp_create: no HIP device available (this library has no CPU fallback)");
     if (device_id < 0 || device_id >= count) return fail(nullptr, NPP_ERR_INVALID, "npp_create: bad device_id");
-    HIP_TRY(nullptr, hipSetDevice(device_id));
+    DeviceGuard dg(device_id);
+    if (dg.err != hipSuccess) return fail(nullptr, NPP_ERR_HIP, std::string("npp_create: hipSetDevice: ") + hipGetErrorString(dg.err));
     npp_handle h = new npp_handle_s();
     h->n = n_envs;
     h->device = device_id;
@@ -218,7 +252,7 @@ int npp_create(int n_envs, int device_id, unsigned flags, npp_handle *out) {
 
 int npp_destroy(npp_handle h) {
     if (!h) return NPP_OK;
-    hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache);
@@ -235,6 +269,7 @@ int npp_set_stream(npp_handle h, void *hip_stream) {
 
 int npp_sync(npp_handle h) {
     if (!h) return NPP_ERR_INVALID;
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NPP_OK;
 }
@@ -242,7 +277,7 @@ int npp_sync(npp_handle h) {
 int npp_snapshot(npp_handle h) {
     if (!h) return NPP_ERR_INVALID;
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_snapshot: no levels loaded");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     size_t N = (size_t)h->n;
     if (!h->s_f64) {
         HIP_TRY(h, hipMalloc((void **)&h->s_f64, sizeof(double) * NF64 * N));
@@ -263,6 +298,7 @@ int npp_snapshot(npp_handle h) {
         if (!h->s_zoo) HIP_TRY(h, hipMalloc((void **)&h->s_zoo, sizeof(double) * (size_t)h->zoo_words * N));
         HIP_TRY(h, hipMemcpyAsync(h->s_zoo, h->d_zoo, sizeof(double) * (size_t)h->zoo_words * N, hipMemcpyDeviceToDevice, h->stream));
     }
+    h->s_ovr = h->ovr;
     h->s_gen = h->assign_gen;
     return NPP_OK;
 }
@@ -271,7 +307,7 @@ int npp_restore(npp_handle h, const uint8_t *env_mask) {
     if (!h) return NPP_ERR_INVALID;
     if (!h->s_f64 || h->s_gen != h->assign_gen)
         return fail(h, NPP_ERR_STATE, "npp_restore: no snapshot for the current level assignment");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     if (env_mask) {
         HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
@@ -279,6 +315,15 @@ int npp_restore(npp_handle h, const uint8_t *env_mask) {
     }
     HIP_TRY(h, launch_restore(a, h->s_f64, h->s_u32, h->s_ent, h->s_sc, h->d_zoo ? h->s_zoo : nullptr, h->stream));
     if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // the restored zoo blocks carry the repositioning flags / coordinates of the snapshot (head words 3..7): the host's
+    // view of them (which decides whether the zoo kernels run) is restored with them
+    if (h->s_ovr.size() == h->ovr.size()) {
+        for (int e = 0; e < h->n; e++)
+            if (!env_mask || env_mask[e]) h->ovr[e] = h->s_ovr[e];
+        h->n_ovr = 0;
+        for (int e = 0; e < h->n; e++) h->n_ovr += h->ovr[e] != 0;
+        plan_geometry(h);
+    }
     return NPP_OK;
 }
 
@@ -304,7 +349,7 @@ int npp_num_levels(npp_handle h) { return h ? (int)h->levels.size() : 0; }
 
 int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, int n_levels) {
     if (!h || !blob || !offsets || n_levels <= 0) return fail(h, NPP_ERR_INVALID, "npp_load_levels: bad arguments");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     std::vector<CompiledLevel> lv(n_levels);
     for (int i = 0; i < n_levels; i++) {
         std::string err;
@@ -395,6 +440,10 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     hipFree(h->d_zoo); h->d_zoo = nullptr;
     hipFree(h->s_zoo); h->s_zoo = nullptr;
     (void)any_zoo;
+    zoo_block_plan(lv, zoo_doors, zoo_movers);
+    for (int i = 0; i < n_levels; i++)   // round-1 fault: a block sized over zoo levels only was overrun
+        if ((int)hdrs[i].n_zdoor > zoo_doors || (int)hdrs[i].n_mov > zoo_movers)
+            return fail(h, NPP_ERR_STATE, "npp_load_levels: zoo block plan does not cover level " + std::to_string(i));
     h->zoo_words = zoo_words_for(zoo_doors, zoo_movers);
     h->zoo_doors = zoo_doors;
     h->zoo_movers = zoo_movers;
@@ -426,28 +475,38 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
     if (!h || !level_ids || n <= 0) return fail(h, NPP_ERR_INVALID, "npp_assign_levels: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_assign_levels: no levels loaded");
     if (!env_ids && n != h->n) return fail(h, NPP_ERR_INVALID, "npp_assign_levels: env_ids == NULL needs n == n_envs");
+    ON_DEVICE(h);
     std::vector<uint8_t> mask(h->n, 0);
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++) {   // validate everything before touching the assignment: an error must leave host and device in step
         int e = env_ids ? env_ids[i] : i;
         if (e < 0 || e >= h->n || level_ids[i] < 0 || level_ids[i] >= (int)h->levels.size())
             return fail(h, NPP_ERR_INVALID, "npp_assign_levels: index out of range");
+    }
+    for (int i = 0; i < n; i++) {
+        int e = env_ids ? env_ids[i] : i;
         h->env_level[e] = level_ids[i];
         mask[e] = 1;
         if (!h->ovr.empty() && h->ovr[e]) { h->ovr[e] = 0; h->n_ovr--; }   // a new level: nothing is repositioned
     }
     h->assign_gen++;
     plan_geometry(h);
-    HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_env_level, h->env_level.data(), sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
     return reset_impl(h, mask.data(), 1);
 }
 
-int npp_reset(npp_handle h, const uint8_t *env_mask) { return reset_impl(h, env_mask, 0); }
+int npp_reset(npp_handle h, const uint8_t *env_mask) { return npp_reset_ex(h, env_mask, 0); }
+
+int npp_reset_ex(npp_handle h, const uint8_t *env_mask, int mode) {
+    if (!h) return NPP_ERR_INVALID;
+    if (mode < 0 || mode > 2) return fail(h, NPP_ERR_INVALID, "npp_reset_ex: mode must be 0, 1 or 2");
+    const int fast = mode == 2 || (mode == 0 && (h->flags & NPP_FLAG_FAST_RESET));
+    return reset_impl(h, env_mask, 0, fast ? 1 : 0);
+}
 
 int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
     if (!h) return NPP_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     std::vector<int32_t> lim;
     if (!limits) { lim.assign(h->n, all); limits = lim.data(); }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -458,6 +517,7 @@ int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
 int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_step_out *out) {
     if (!h || !d_actions || frame_skip <= 0) return fail(h, NPP_ERR_INVALID, "npp_step: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_step: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     a.inputs = d_actions;
     a.n_ticks = frame_skip;
@@ -470,6 +530,7 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
 int npp_step_many(npp_handle h, const uint8_t *d_actions, int n_steps, int frame_skip, const npp_step_out *out) {
     if (!h || !d_actions || frame_skip <= 0 || n_steps <= 0) return fail(h, NPP_ERR_INVALID, "npp_step_many: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_step_many: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     a.inputs = d_actions;
     a.n_ticks = frame_skip;
@@ -484,6 +545,7 @@ int npp_step_many(npp_handle h, const uint8_t *d_actions, int n_steps, int frame
 int npp_tick(npp_handle h, const uint8_t *d_inputs, int n_ticks) {
     if (!h || !d_inputs || n_ticks <= 0) return fail(h, NPP_ERR_INVALID, "npp_tick: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_tick: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     a.inputs = d_inputs;
     a.n_ticks = n_ticks;
@@ -496,6 +558,7 @@ int npp_tick(npp_handle h, const uint8_t *d_inputs, int n_ticks) {
 int npp_observe(npp_handle h, const npp_step_out *out) {
     if (!h || !out) return fail(h, NPP_ERR_INVALID, "npp_observe: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_observe: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     a.n_ticks = 0;
     a.mode = 0;
@@ -508,6 +571,7 @@ int npp_observe(npp_handle h, const npp_step_out *out) {
 int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_player_frame: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_player_frame: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_render(a, d_out, (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0, h->stream));
     return NPP_OK;
@@ -518,7 +582,7 @@ int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y) {
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_set_entity_pos: no levels loaded");
     const CompiledLevel &L = h->levels[h->env_level[env]];
     if (L.obs_switch < 0) return fail(h, NPP_ERR_STATE, "npp_set_entity_pos: the env's level has no exit switch / door");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     double *blk = h->d_zoo + (size_t)env * h->zoo_words;
     uint64_t w3 = 0;
@@ -543,6 +607,7 @@ int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y) {
 int npp_switch_states(npp_handle h, float *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_switch_states: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_switch_states: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_switch_states(a, d_out, h->stream));
     return NPP_OK;
@@ -551,6 +616,7 @@ int npp_switch_states(npp_handle h, float *d_out) {
 int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out) {
     if (!h || !d_out || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_render_frame: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_frame: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_full_frame(a, env0, count, d_out, h->stream));
     return NPP_OK;
@@ -559,6 +625,7 @@ int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out) {
 int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_global_view: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_global_view: no levels loaded");
+    ON_DEVICE(h);
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_global_view(a, d_out, h->stream));
     return NPP_OK;
@@ -567,7 +634,7 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
 int npp_dump_state(npp_handle h, int env0, int count, double *f64_out, int32_t *i32_out) {
     if (!h || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_dump_state: bad range");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_dump_state: no levels loaded");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     size_t N = (size_t)h->n;
     std::vector<double> f((size_t)NF64 * count);
@@ -615,7 +682,7 @@ int npp_dump_state(npp_handle h, int env0, int count, double *f64_out, int32_t *
 int npp_dump_entities(npp_handle h, int env, int32_t *out, int max, int *n_out) {
     if (!h || env < 0 || env >= h->n || !out || !n_out) return fail(h, NPP_ERR_INVALID, "npp_dump_entities: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_dump_entities: no levels loaded");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const CompiledLevel &L = h->levels[h->env_level[env]];
     std::vector<uint32_t> w(h->n_words_max);
@@ -634,7 +701,7 @@ int npp_dump_entities(npp_handle h, int env, int32_t *out, int max, int *n_out) 
 int npp_entity_checksum(npp_handle h, int env0, int count, double *out) {
     if (!h || env0 < 0 || count <= 0 || env0 + count > h->n || !out) return fail(h, NPP_ERR_INVALID, "npp_entity_checksum: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_entity_checksum: no levels loaded");
-    HIP_TRY(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     size_t N = (size_t)h->n;
     std::vector<uint32_t> w((size_t)h->n_words_max * count);
@@ -738,6 +805,22 @@ int npp_compile_level_zoo(const double *map, int64_t n, int32_t *edges_out, doub
         }
     }
     *n_movers = nm;
+    return NPP_OK;
+}
+
+int npp_plan_zoo_block(const double *blob, const int64_t *offsets, int n_levels, int *doors, int *movers, int *words) {
+    if (!blob || !offsets || n_levels <= 0) return fail(nullptr, NPP_ERR_INVALID, "npp_plan_zoo_block: bad arguments");
+    std::vector<CompiledLevel> lv(n_levels);
+    for (int i = 0; i < n_levels; i++) {
+        std::string err;
+        if (offsets[i + 1] < offsets[i] || !compile_level(blob + offsets[i], offsets[i + 1] - offsets[i], lv[i], err))
+            return fail(nullptr, NPP_ERR_INVALID, "npp_plan_zoo_block: level " + std::to_string(i) + ": " + err);
+    }
+    int d = 0, m = 0;
+    zoo_block_plan(lv, d, m);
+    if (doors) *doors = d;
+    if (movers) *movers = m;
+    if (words) *words = zoo_words_for(d, m);
     return NPP_OK;
 }
 

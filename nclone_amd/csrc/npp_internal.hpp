@@ -69,6 +69,8 @@ struct StepOut {
     uint16_t *frames;
     float *terminal_state;
     float *spatial_context;
+    double *positions;
+    uint16_t *work;
 };
 
 struct KernelArgs {
@@ -99,6 +101,7 @@ struct KernelArgs {
     int zoo_movers;       // mover slots per env (max over levels)
     int zoo_active;       // 1: some env currently plays a level with zoo entities -> the zoo step kernel runs
     int reset_fresh;      // reset kernel: 1 = this reset is the first creation after a (re)assignment of levels
+    int fast_reset;       // reset kernel: this reset is a Simulator.fast_reset; step kernels: auto-resets are fast resets
     StepOut out;
 };
 

@@ -80,6 +80,7 @@ struct Nj {
     int state, airborn, airborn_old, walled, wn, jio, hor, jump, gjump, dslow;
     int jbuf, fbuf, wbuf, lbuf, cause, timpact;
     int jdur, fcount, ccount, pstate, fair, scf, frame, gold, doors, pcell;
+    int work;   // depenetration iterations applied since the step began (npp_step_out.d_work; not part of the state)
 };
 
 struct Lv {
@@ -156,6 +157,7 @@ DEV void load_state(const KernelArgs &a, int e, Nj &n) {
     n.frame = D & 0xffff; n.gold = (D >> 16) & 255; n.doors = D >> 24;
     n.pcell = E & 0xffff;
     n.scvalid = (E >> 16) & 1;
+    n.work = 0;
 }
 
 DEV int sat(int v, int hi) { return v > hi ? hi : v; }
@@ -680,7 +682,7 @@ DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += d
         double dist = sqrt_inrange(dist_sq); /* garbage when tiny: the exit below does not look at it */ \
         double depen_len = NINJA_RADIUS - (back_facing ? -dist : dist); /* dist * result, exactly */   \
         if (none | tiny | (depen_len < 0.0000001)) BREAK;                                              \
-        (io).applied = 1;                                                                              \
+        (io).applied += 1;                                                                             \
         double inv_dist = rcp_inrange(dist);                                                           \
         double norm_dx = ddx * inv_dist, norm_dy = ddy * inv_dist;                                     \
         const double depen_x = norm_dx * depen_len, depen_y = norm_dy * depen_len;                     \
@@ -730,14 +732,14 @@ __device__ __noinline__ IO depen_generic(TileRefs lv, int r, double gx0, double 
     return io;
 }
 
-// Ninja.collide_vs_tiles (ninja.py:269-379).  Returns true when at least one depenetration was applied.
+// Ninja.collide_vs_tiles (ninja.py:269-379).  Returns the number of depenetrations applied.
 struct Crush { double xcr, ycr, clen; };
 DEV void crush_in(DepenIO &, const Crush &) {}
 DEV void crush_in(DepenIOZ &io, const Crush &c) { io.xcr = c.xcr; io.ycr = c.ycr; io.clen = c.clen; }
 DEV void crush_out(const DepenIO &, Crush &) {}
 DEV void crush_out(const DepenIOZ &io, Crush &c) { c.xcr = io.xcr; c.ycr = io.ycr; c.clen = io.clen; }
 template <int G, int K, bool ZOO>
-DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double xold, double yold, double &fnsx, double &fnsy,
+DEV int collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double xold, double yold, double &fnsx, double &fnsy,
                           double &cnsx, double &cnsy, Crush &cr STAMP_ARG) {
     double dx = n.x - xold, dy = n.y - yold;
     // ---- sweep_circle_vs_tiles (physics.py:104-128); the early `return 0` of the reference equals the minimum
@@ -778,7 +780,7 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
     if (fast) {
 #pragma unroll
         for (int k = 0; k < K; k++) gp |= cand_in_box(cd, k, qg) ? (1u << k) : 0u;
-        if (!group_any<G>(gp != 0)) return false;   // empty list: result == 0 at the first iteration
+        if (!group_any<G>(gp != 0)) return 0;   // empty list: result == 0 at the first iteration
     }
     using IO = typename std::conditional<ZOO, DepenIOZ, DepenIO>::type;
     IO io;
@@ -838,7 +840,7 @@ DEV bool collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double 
     fnsx = io.fnsx; fnsy = io.fnsy; cnsx = io.cnsx; cnsy = io.cnsy;
     n.fcount = io.fcount; n.ccount = io.ccount;
     crush_out(io, cr);
-    return io.applied != 0;
+    return io.applied;
 }
 
 // overlap_circle_vs_circle (physics.py:204-207) with an exact-safe early reject
@@ -1219,9 +1221,10 @@ DEV void sim_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb, int hor,
                 collide_vs_objects<G>(lv, z, r, n, zt, xold, yold, fnsx, fnsy, cnsx, cnsy);
                 cr.xcr = zt.xcr; cr.ycr = zt.ycr; cr.clen = zt.clen;
             }
-            bool applied = collide_vs_tiles<G, K, ZOO>(lv, r, n, cd, xold, yold, fnsx, fnsy, cnsx, cnsy, cr STAMP_PASS);
+            const int applied = collide_vs_tiles<G, K, ZOO>(lv, r, n, cd, xold, yold, fnsx, fnsy, cnsx, cnsy, cr STAMP_PASS);
+            n.work += applied;
             zt.xcr = cr.xcr; zt.ycr = cr.ycr; zt.clen = cr.clen;
-            if (!(zoo && zt.phys_near) && !applied && n.x == xb && n.y == yb) break;
+            if (!(zoo && zt.phys_near) && applied == 0 && n.x == xb && n.y == yb) break;
         }
         STAMP(4);
         post_collision<G, K, ZOO>(lv, z, r, n, cd, eb, fnsx, fnsy, cnsx, cnsy, xold, yold, zt);
@@ -1503,6 +1506,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 #pragma nounroll
     for (int sidx = 0; sidx < n_steps; sidx++) {
         flags = 0; executed = 0; reward = 0.f;
+        n.work = 0;
         const bool had_switch = lv.obs_switch >= 0 && ent_get(eb, lv.obs_switch) == 0;
         {
             // mode 0: NppEnvironment.step frame-skip loop (base_environment.py:524-609), action table :366-402; an env that
@@ -1548,6 +1552,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
             if (a.out.flags) a.out.flags[o] = (uint8_t)flags;
             if (a.out.reward) a.out.reward[o] = reward;
             if (a.out.frames) a.out.frames[o] = (uint16_t)executed;
+            if (a.out.work) a.out.work[o] = (uint16_t)(n.work > 0xffff ? 0xffff : n.work);
         }
         if (MANY && sidx + 1 < n_steps && a.autoreset && stepping && done) {   // intermediate steps reset on the spot
             spawn_state(lv, n);
@@ -1592,6 +1597,10 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         block_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.entity_pos + (size_t)env0 * 6), 6, n_valid);
         __syncthreads();
     }
+    if (a.out.positions && writer) {   // pass-through scalars player_x/y, switch_x/y, exit_door_x/y (unrounded)
+        double *row = a.out.positions + (size_t)env * 6;
+        row[0] = n.x; row[1] = n.y; row[2] = lv.sw_x; row[3] = lv.sw_y; row[4] = lv.door_x; row[5] = lv.door_y;
+    }
     if (a.out.spatial_context) write_spatial_context<G>(a, H, n, eb, env, r, valid);
     if (a.out.action_mask && writer) {
         uint32_t m = action_mask_bits(n);
@@ -1623,8 +1632,14 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 
 // LDS_LEVEL is chosen by the host: true when every workgroup's envs play one level that fits the LDS budget
 // (the host knows the env -> level assignment), false otherwise (tables are read through L1/L2).
+// Register budget: the second launch-bound argument is the minimum number of wavefronts per SIMD.  Two per SIMD (<= 256
+// unified VGPR + AGPR) keep all 2048 wavefronts of an 8192-env launch resident at once (1024 SIMDs); the zoo kernels carry
+// far more state and stay at one.
+#ifndef NPP_MIN_WAVES
+#define NPP_MIN_WAVES 2
+#endif
 template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
-__global__ __launch_bounds__(256) void npp_step_kernel(KernelArgs a) {
+__global__ __launch_bounds__(256, (ZOO ? 1 : NPP_MIN_WAVES)) void npp_step_kernel(KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     run<G, LDS_LEVEL, ZOO, MANY>(a, smem);
 }
@@ -1652,6 +1667,9 @@ __global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
         z.door_tab = reinterpret_cast<const uint32_t *>(a.blob + H.off_door_tab);
         z.n_mov = (int)H.n_mov; z.n_door = (int)H.n_zdoor; z.door_words = (a.zoo_doors + 1) / 2;
         z.n_created = (int)H.n_created;
+        // never write outside this env's block, whatever the host planned (npp_load_levels checks the plan as well)
+        if (z.n_door > a.zoo_doors) z.n_door = a.zoo_doors;
+        if (z.n_mov > a.zoo_movers) z.n_mov = a.zoo_movers;
         zoo_init_block(z, 0, 1, a.reset_fresh != 0);
     }
 }
@@ -1693,6 +1711,10 @@ hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
 
 template <bool Z, bool M>
 hipError_t launch_step_zm(const KernelArgs &a, hipStream_t s) {
+#ifdef NPP_ONLY_G   // experiments (tools/regs_experiment.sh): one instantiation compiles in seconds
+    if (a.lanes_per_env == NPP_ONLY_G) return launch_step_g<NPP_ONLY_G, Z, M>(a, s);
+    return hipErrorInvalidValue;
+#else
     switch (a.lanes_per_env) {
         case 1: return launch_step_g<1, Z, M>(a, s);
         case 2: return launch_step_g<2, Z, M>(a, s);
@@ -1703,6 +1725,7 @@ hipError_t launch_step_zm(const KernelArgs &a, hipStream_t s) {
         case 64: return launch_step_g<64, Z, M>(a, s);
         default: return hipErrorInvalidValue;
     }
+#endif
 }
 
 }  // namespace

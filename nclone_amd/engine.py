@@ -11,6 +11,22 @@ import torch
 from . import _native as nat
 
 
+class _DeviceStream:
+    """torch.cuda.device + torch.cuda.stream in one context manager."""
+
+    def __init__(self, device, stream):
+        self._d = torch.cuda.device(device)
+        self._s = torch.cuda.stream(stream)
+
+    def __enter__(self):
+        self._d.__enter__()
+        self._s.__enter__()
+
+    def __exit__(self, *a):
+        self._s.__exit__(*a)
+        self._d.__exit__(*a)
+
+
 def _as_f64_blob(levels):
     """levels: sequence of 1-D arrays/lists/bytes of raw map_data values -> (blob f64, offsets i64)."""
     arrs = []
@@ -25,20 +41,101 @@ def _as_f64_blob(levels):
     return blob, offsets
 
 
+# every output the kernels can produce: name -> (per-env shape, dtype).  The first six are the packed observation block
+# of BASELINE.json config 4 (what a learner on another GPU needs each step); they sit first and contiguous in the block.
+_FIELDS = {
+    "game_state": ((41,), torch.float32),
+    "entity_pos": ((6,), torch.float32),
+    "reward": ((), torch.float32),
+    "frames": ((), torch.int16),
+    "action_mask": ((6,), torch.int8),
+    "flags": ((), torch.uint8),
+    "terminal_state": ((41,), torch.float32),
+    "spatial_context": ((112,), torch.float32),
+    "positions": ((6,), torch.float64),
+    "work": ((), torch.int16),
+    "switch_states": ((25,), torch.float32),
+    "player_frame": ((84, 84, 1), torch.uint8),
+    "global_view": ((176, 100, 1), torch.uint8),
+}
+_ALWAYS = ("game_state", "entity_pos", "reward", "frames", "action_mask", "flags", "terminal_state")
+_PACKED = ("game_state", "entity_pos", "reward", "frames", "action_mask", "flags")
+_OPTIONAL = ("spatial_context", "positions", "work", "switch_states", "player_frame", "global_view")
+
+
+class OutputBlock:
+    """All enabled outputs of one handle in ONE contiguous device allocation (each field 256-byte aligned), plus two pinned
+    host mirrors.  One block means: one RCCL all_gather moves the whole packed observation of a rank (config 4), and one
+    asynchronous device-to-host copy + one synchronisation serves a numpy training loop (`to_host`)."""
+
+    def __init__(self, n, device, names):
+        self.n = int(n)
+        self.names = [k for k in _FIELDS if k in names]   # canonical order: packed observation first
+        self.offsets = {}
+        off = 0
+        for k in self.names:
+            shape, dt = _FIELDS[k]
+            nbytes = self.n * int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dt).element_size()
+            self.offsets[k] = (off, nbytes)
+            off = (off + nbytes + 255) // 256 * 256
+            if k == _PACKED[-1]:
+                self.packed_bytes = off
+        self.nbytes = off
+        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.t = {k: self._view(self.dev, k) for k in self.names}
+        self._host = [None, None]
+        self._flip = 0
+
+    def _view(self, base, k):
+        off, nbytes = self.offsets[k]
+        shape, dt = _FIELDS[k]
+        return base[off:off + nbytes].view(dt).view((self.n,) + tuple(shape))
+
+    def packed(self):
+        """uint8 view of the packed observation (game_state, entity_pos, reward, frames, action_mask, flags)."""
+        return self.dev[:self.packed_bytes]
+
+    def split_packed(self, gathered, world):
+        """Views into an all-gathered [world * packed_bytes] uint8 tensor: {name: [world, n, ...]}."""
+        g = gathered.view(world, self.packed_bytes)
+        out = {}
+        for k in _PACKED:
+            off, nbytes = self.offsets[k]
+            shape, dt = _FIELDS[k]
+            out[k] = g[:, off:off + nbytes].contiguous().view(dt).view((world, self.n) + tuple(shape))
+        return out
+
+    def to_host(self, stream, names=None):
+        """One async copy of the block (up to the last requested field) into a pinned mirror on `stream`, one
+        synchronisation; returns {name: numpy view}.  Two mirrors alternate, so the arrays of the previous call stay valid
+        until the call after this one (obs_t and obs_t+1 can be held together)."""
+        names = self.names if names is None else [k for k in self.names if k in names]
+        end = max(self.offsets[k][0] + self.offsets[k][1] for k in names)
+        if self._host[self._flip] is None:
+            self._host[self._flip] = torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True)
+        host = self._host[self._flip]
+        self._flip ^= 1
+        with torch.cuda.stream(stream):
+            host[:end].copy_(self.dev[:end], non_blocking=True)
+        stream.synchronize()
+        return {k: self._view(host, k).numpy() for k in names}
+
+
 class NppBatch:
     """N environments stepped in lock-step on one GPU.
 
     Counterpart of N instances of the reference's NPlayHeadless (nclone/nplay_headless.py:28).
     """
 
-    def __init__(self, n_envs, device=0, autoreset=True, allow_unsupported=False, frame_centered=False, stream=None):
+    def __init__(self, n_envs, device=0, autoreset=True, allow_unsupported=False, frame_centered=False, stream=None,
+                 outputs=(), fast_reset=False):
         self.lib = nat.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("nclone_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.n = int(n_envs)
         self.device = torch.device("cuda", int(device))
         flags = ((nat.FLAG_AUTORESET if autoreset else 0) | (nat.FLAG_ALLOW_UNSUPPORTED if allow_unsupported else 0)
-                 | (nat.FLAG_FRAME_CENTERED if frame_centered else 0))
+                 | (nat.FLAG_FRAME_CENTERED if frame_centered else 0) | (nat.FLAG_FAST_RESET if fast_reset else 0))
         h = C.c_void_p()
         nat.check(None, self.lib.npp_create(self.n, int(device), flags, C.byref(h)))
         self.h = h
@@ -47,28 +144,49 @@ class NppBatch:
             # every launch of this handle is ordered on ONE HIP stream; handles on different streams overlap on the GPU
             self.stream = stream if stream is not None else torch.cuda.current_stream()
             nat.check(self.h, self.lib.npp_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
-            N = self.n
-            self.game_state = torch.zeros((N, 41), dtype=torch.float32, device=self.device)
-            self.action_mask = torch.zeros((N, 6), dtype=torch.int8, device=self.device)
-            self.entity_pos = torch.zeros((N, 6), dtype=torch.float32, device=self.device)
-            self.flags = torch.zeros((N,), dtype=torch.uint8, device=self.device)
-            self.reward = torch.zeros((N,), dtype=torch.float32, device=self.device)
-            self.frames = torch.zeros((N,), dtype=torch.int16, device=self.device)
-            self.terminal_state = torch.zeros((N, 41), dtype=torch.float32, device=self.device)
-            self.spatial_context = None   # allocated by enable_spatial_context()
-        self._out = nat.StepOut(
-            self.game_state.data_ptr(), self.action_mask.data_ptr(), self.entity_pos.data_ptr(), self.flags.data_ptr(),
-            self.reward.data_ptr(), self.frames.data_ptr(), self.terminal_state.data_ptr(), None,
-        )
-        self._out_min = nat.StepOut(self.game_state.data_ptr(), self.action_mask.data_ptr(), self.entity_pos.data_ptr(),
-                                    self.flags.data_ptr(), self.reward.data_ptr(), self.frames.data_ptr(), None, None)
+        self._enabled = set(_ALWAYS)
+        for k in outputs:
+            if k not in _OPTIONAL:
+                raise ValueError("unknown output %r (optional outputs: %s)" % (k, ", ".join(_OPTIONAL)))
+            self._enabled.add(k)
+        self._build_block()
+
+    def _build_block(self):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            self.out = OutputBlock(self.n, self.device, self._enabled)
+        t = self.out.t
+        self.game_state, self.action_mask, self.entity_pos = t["game_state"], t["action_mask"], t["entity_pos"]
+        self.flags, self.reward, self.frames, self.terminal_state = t["flags"], t["reward"], t["frames"], t["terminal_state"]
+        self.spatial_context = t.get("spatial_context")
+        self.positions = t.get("positions")
+        self.work = t.get("work")
+
+        def ptr(k):
+            return t[k].data_ptr() if k in t else None
+
+        self._out = nat.StepOut(ptr("game_state"), ptr("action_mask"), ptr("entity_pos"), ptr("flags"), ptr("reward"),
+                                ptr("frames"), ptr("terminal_state"), ptr("spatial_context"), ptr("positions"), ptr("work"))
+        self._out_min = nat.StepOut(ptr("game_state"), ptr("action_mask"), ptr("entity_pos"), ptr("flags"), ptr("reward"),
+                                    ptr("frames"), None, ptr("spatial_context"), ptr("positions"), ptr("work"))
+
+    def enable_outputs(self, *names):
+        """Add optional outputs (spatial_context, positions, work, switch_states, player_frame, global_view); the output
+        block is re-allocated, so tensors obtained earlier are stale."""
+        new = [k for k in names if k not in self._enabled]
+        for k in new:
+            if k not in _OPTIONAL:
+                raise ValueError("unknown output %r" % (k,))
+            self._enabled.add(k)
+        if new:
+            self._build_block()
 
     def enable_spatial_context(self):
         """Also produce the 112-float spatial_context observation (8x8 tile categories + 8 nearest mines)."""
-        if self.spatial_context is None:
-            self.spatial_context = torch.zeros((self.n, 112), dtype=torch.float32, device=self.device)
-            self._out.d_spatial_context = self.spatial_context.data_ptr()
-            self._out_min.d_spatial_context = self.spatial_context.data_ptr()
+        self.enable_outputs("spatial_context")
+
+    def _ctx(self):
+        """Launches, copies and allocations of this handle run with its device current and on its stream."""
+        return _DeviceStream(self.device, self.stream)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -114,18 +232,28 @@ class NppBatch:
         return g.value, w.value
 
     # ---- stepping ---------------------------------------------------------------------------------------------
-    def reset(self, mask=None):
+    def reset(self, mask=None, mode="default"):
+        """mode: "default" (the handle's NPP_FLAG_FAST_RESET decides), "full" (Simulator.reset), "fast" (fast_reset)."""
+        code = {"default": 0, "full": 1, "fast": 2}[mode]
         if mask is None:
-            nat.check(self.h, self.lib.npp_reset(self.h, None))
+            nat.check(self.h, self.lib.npp_reset_ex(self.h, None, code))
         else:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
             assert len(m) == self.n
-            nat.check(self.h, self.lib.npp_reset(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+            nat.check(self.h, self.lib.npp_reset_ex(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)), code))
 
-    def step(self, actions, frame_skip=4, want_terminal=True):
-        """actions: uint8 CUDA tensor [N] with values 0..5.  Asynchronous; outputs land in self.game_state etc."""
+    def step(self, actions, frame_skip=4, want_terminal=True, work_out=None):
+        """actions: uint8 CUDA tensor [N] with values 0..5.  Asynchronous; outputs land in self.game_state etc.
+        work_out: optional int16 CUDA tensor [N] that receives this step's per-env depenetration iteration counts (instead
+        of the block's `work` field) -- lets a profiler keep one row per step."""
         assert actions.dtype == torch.uint8 and actions.is_cuda and actions.numel() == self.n
         out = self._out if want_terminal else self._out_min
+        if work_out is not None:
+            assert work_out.dtype == torch.int16 and work_out.is_cuda and work_out.numel() == self.n and work_out.is_contiguous()
+            tmp = nat.StepOut()
+            C.memmove(C.byref(tmp), C.byref(out), C.sizeof(nat.StepOut))
+            tmp.d_work = work_out.data_ptr()
+            out = tmp
         nat.check(self.h, self.lib.npp_step(self.h, C.c_void_p(actions.data_ptr()), int(frame_skip), C.byref(out)))
 
     def step_many(self, actions, frame_skip=4):
@@ -133,17 +261,19 @@ class NppBatch:
         plans).  Returns (flags u8 [K, N], reward f32 [K, N], frames i16 [K, N]); observations of the last step land in
         self.game_state etc.; with auto-reset, envs that terminate mid-sequence restart on the spot."""
         assert actions.dtype == torch.uint8 and actions.is_cuda and actions.dim() == 2 and actions.shape[1] == self.n
-        actions = actions.contiguous()
         K = int(actions.shape[0])
-        flags = torch.zeros((K, self.n), dtype=torch.uint8, device=self.device)
-        reward = torch.zeros((K, self.n), dtype=torch.float32, device=self.device)
-        frames = torch.zeros((K, self.n), dtype=torch.int16, device=self.device)
-        out = nat.StepOut(self.game_state.data_ptr(), self.action_mask.data_ptr(), self.entity_pos.data_ptr(), flags.data_ptr(),
-                          reward.data_ptr(), frames.data_ptr(), None,
-                          self.spatial_context.data_ptr() if self.spatial_context is not None else None)
-        nat.check(self.h, self.lib.npp_step_many(self.h, C.c_void_p(actions.data_ptr()), K, int(frame_skip), C.byref(out)))
-        self._keep = actions
-        self.flags.copy_(flags[-1]); self.reward.copy_(reward[-1]); self.frames.copy_(frames[-1])
+        with self._ctx():   # allocations, the launch and the copies below are all ordered on the handle's stream
+            actions = actions.contiguous()
+            flags = torch.zeros((K, self.n), dtype=torch.uint8, device=self.device)
+            reward = torch.zeros((K, self.n), dtype=torch.float32, device=self.device)
+            frames = torch.zeros((K, self.n), dtype=torch.int16, device=self.device)
+            out = nat.StepOut(self.game_state.data_ptr(), self.action_mask.data_ptr(), self.entity_pos.data_ptr(), flags.data_ptr(),
+                              reward.data_ptr(), frames.data_ptr(), None,
+                              self.spatial_context.data_ptr() if self.spatial_context is not None else None,
+                              self.positions.data_ptr() if self.positions is not None else None, None)
+            nat.check(self.h, self.lib.npp_step_many(self.h, C.c_void_p(actions.data_ptr()), K, int(frame_skip), C.byref(out)))
+            self._keep = actions
+            self.flags.copy_(flags[-1]); self.reward.copy_(reward[-1]); self.frames.copy_(frames[-1])
         return flags, reward, frames
 
     def tick(self, inputs):
@@ -156,8 +286,11 @@ class NppBatch:
     def observe(self):
         nat.check(self.h, self.lib.npp_observe(self.h, C.byref(self._out_min)))
 
-    def render_player_frame(self, out):
-        """out: uint8 CUDA tensor [N, 84, 84] (or [N, 84, 84, 1]) filled with the player_frame of every env."""
+    def render_player_frame(self, out=None):
+        """out: uint8 CUDA tensor [N, 84, 84] (or [N, 84, 84, 1]) filled with the player_frame of every env; default: the
+        output block's player_frame field (enable_outputs("player_frame"))."""
+        if out is None:
+            out = self.out.t["player_frame"]
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 84 * 84 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_render_player_frame(self.h, C.c_void_p(out.data_ptr())))
 
@@ -168,19 +301,25 @@ class NppBatch:
     def switch_states(self, out=None):
         """float32 CUDA tensor [N, 25]: the reference's switch_states observation (5 locked doors x 5 features)."""
         if out is None:
-            out = torch.zeros((self.n, 25), dtype=torch.float32, device=self.device)
+            out = self.out.t.get("switch_states")
+        if out is None:
+            with self._ctx():
+                out = torch.zeros((self.n, 25), dtype=torch.float32, device=self.device)
         assert out.dtype == torch.float32 and out.is_cuda and out.numel() == self.n * 25 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_switch_states(self.h, C.c_void_p(out.data_ptr())))
         return out
 
     def render_frame(self, env0=0, count=1):
         """uint8 CUDA tensor [count, 600, 1056, 1]: the whole gray frame (the reference's render() array) of some envs."""
-        out = torch.zeros((count, 600, 1056, 1), dtype=torch.uint8, device=self.device)
+        with self._ctx():
+            out = torch.zeros((count, 600, 1056, 1), dtype=torch.uint8, device=self.device)
         nat.check(self.h, self.lib.npp_render_frame(self.h, int(env0), int(count), C.c_void_p(out.data_ptr())))
         return out
 
-    def render_global_view(self, out):
+    def render_global_view(self, out=None):
         """out: uint8 CUDA tensor [N, 176, 100] (or [N, 176, 100, 1]): the reference's global_view of every env."""
+        if out is None:
+            out = self.out.t["global_view"]
         assert out.dtype == torch.uint8 and out.is_cuda and out.numel() == self.n * 176 * 100 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_render_global_view(self.h, C.c_void_p(out.data_ptr())))
 
@@ -203,6 +342,12 @@ class NppBatch:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
             assert len(m) == self.n
             nat.check(self.h, self.lib.npp_restore(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def to_host(self, names=None):
+        """{name: numpy array} of the enabled outputs through ONE async device-to-host copy of the output block into pinned
+        memory on the handle's stream + one synchronisation.  The arrays are views of a pinned staging block; two blocks
+        alternate, so they stay valid until the to_host() call after the next one."""
+        return self.out.to_host(self.stream, names)
 
     def sync(self):
         nat.check(self.h, self.lib.npp_sync(self.h))

@@ -43,18 +43,10 @@ class CompactReplay:
 
 
 def decode_input_to_controls(input_byte):
-    jump = 1 if (input_byte & 0x01) else 0
-    right = 1 if (input_byte & 0x02) else 0
-    left = 1 if (input_byte & 0x04) else 0
-    if left and right:
-        horizontal = 0
-    elif left:
-        horizontal = -1
-    elif right:
-        horizontal = 1
-    else:
-        horizontal = 0
-    return horizontal, jump
+    """Replay input byte -> (horizontal, jump): bit 0 jump, bit 1 right, bit 2 left; left + right cancel
+    (the recorder's format, replay/gameplay_recorder.py:67-129)."""
+    b = int(input_byte)
+    return ((b >> 1) & 1) - ((b >> 2) & 1), b & 1
 
 
 def validate_replays(replays, device=0):

@@ -49,82 +49,111 @@ class NppVecEnvironment:
 
     def __init__(self, levels, num_envs, level_ids=None, frame_skip=4, device=0, enable_visual_observations=False,
                  truncation_limit=10000, output="torch", autoreset=True, enable_spatial_context=False,
-                 enable_switch_states=False):
+                 enable_switch_states=False, fast_reset=True, stream=None):
         assert output in ("torch", "numpy")
         self.num_envs = int(num_envs)
         self.frame_skip = int(frame_skip)
         self.output = output
         self.enable_visual_observations = bool(enable_visual_observations)
         self.single_action_space = spaces.action_space()
-        self.single_observation_space = spaces.observation_space(self.enable_visual_observations)
+        self.single_observation_space = spaces.observation_space(self.enable_visual_observations,
+                                                                 spatial_context=bool(enable_spatial_context),
+                                                                 switch_states=bool(enable_switch_states))
         self.action_space = self.single_action_space
         self.observation_space = self.single_observation_space
-        self._b = NppBatch(self.num_envs, device=device, autoreset=autoreset)
+        outputs = ["positions"]
+        if enable_spatial_context:
+            outputs.append("spatial_context")
+        if enable_switch_states:
+            outputs.append("switch_states")
+        if self.enable_visual_observations:
+            outputs += ["player_frame", "global_view"]
+        # same-level resets are Simulator.fast_reset in the reference's env (npp_environment.py:541-557): the default here
+        self._b = NppBatch(self.num_envs, device=device, autoreset=autoreset, outputs=outputs, fast_reset=fast_reset,
+                           stream=stream)
         self._b.load_levels(levels)
         if level_ids is None:
             level_ids = (np.arange(self.num_envs) // 64) % len(levels)
         self._b.assign_levels(level_ids)
         self._b.set_truncation_limit(truncation_limit)
-        if enable_spatial_context:
-            self._b.enable_spatial_context()
-        self._switch_states = (torch.zeros((self.num_envs, 25), dtype=torch.float32, device=self._b.device)
-                               if enable_switch_states else None)
-        self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
-        self._frame = None
-        if self.enable_visual_observations:
-            self._frame = torch.zeros((self.num_envs, 84, 84, 1), dtype=torch.uint8, device=self._b.device)
-            self._global = torch.zeros((self.num_envs, 176, 100, 1), dtype=torch.uint8, device=self._b.device)
+        with self._b._ctx():
+            self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
+        self._obs_names = ["game_state", "action_mask", "entity_pos", "positions", "flags"] + outputs[1:]
 
     # -- helpers ------------------------------------------------------------------------------------------------
-    def _conv(self, t):
-        return t if self.output == "torch" else t.cpu().numpy()
-
-    def _obs(self):
+    def _produce(self):
+        """Launch the secondary observation kernels (frames, switch_states) on the handle's stream."""
         b = self._b
+        if "switch_states" in b.out.t:
+            b.switch_states()
+        if "player_frame" in b.out.t:
+            b.render_player_frame()
+            b.render_global_view()
+
+    def _obs(self, src):
+        """src: {name: tensor-or-array} (device tensors, or the host views of ONE staged copy)."""
+        pos = src["positions"]
         obs = {
-            "game_state": self._conv(b.game_state),
-            "action_mask": self._conv(b.action_mask),
-            "entity_positions": self._conv(b.entity_pos),
+            "game_state": src["game_state"],
+            "action_mask": src["action_mask"],
+            "entity_positions": src["entity_pos"],
+            # pass-through scalars of the raw observation (observation_processor.py:374-399), unrounded fp64
+            "player_x": pos[:, 0], "player_y": pos[:, 1], "switch_x": pos[:, 2], "switch_y": pos[:, 3],
+            "exit_door_x": pos[:, 4], "exit_door_y": pos[:, 5],
+            "switch_activated": (src["flags"] & 4) != 0,
         }
-        if b.spatial_context is not None:
-            obs["spatial_context"] = self._conv(b.spatial_context)
-        if self._switch_states is not None:
-            obs["switch_states"] = self._conv(b.switch_states(self._switch_states))
-        if self._frame is not None:
-            b.render_player_frame(self._frame)
-            obs["player_frame"] = self._conv(self._frame)
-            b.render_global_view(self._global)
-            obs["global_view"] = self._conv(self._global)
+        for k in ("spatial_context", "switch_states", "player_frame", "global_view"):
+            if k in src:
+                obs[k] = src[k]
         return obs
 
     # -- Gymnasium surface ----------------------------------------------------------------------------------------
     def reset(self, seed=None, options=None):
-        """Reset every env to its level's spawn state (npp_environment.py:504; fast path nsim.py:78)."""
+        """Reset every env to its level's spawn state (npp_environment.py:504).  The first reset of a level assignment is
+        Simulator.reset (nsim.py:62); later ones are Simulator.fast_reset (nsim.py:78) unless fast_reset=False."""
         self._b.reset()
         self._b.observe()
-        return self._obs(), {}
+        self._produce()
+        if self.output == "torch":
+            return self._obs(self._b.out.t), {}
+        return self._obs(self._b.to_host(self._obs_names)), {}
+
+    def step_async(self, actions):
+        """Enqueue the step (action upload, step kernel, observation kernels) on the handle's stream; returns at once."""
+        b = self._b
+        with b._ctx():
+            if isinstance(actions, torch.Tensor):
+                self._actions.copy_(actions.to(torch.uint8), non_blocking=True)
+            else:
+                self._actions.copy_(torch.as_tensor(np.asarray(actions, dtype=np.uint8)), non_blocking=True)
+        b.step(self._actions, self.frame_skip, want_terminal=True)
+        self._produce()
+
+    def step_wait(self):
+        """Results of the step enqueued by step_async: (obs, reward, terminated, truncated, info) with batch dims.
+        output="torch": device tensors, no synchronisation (consume them on the handle's stream);
+        output="numpy": ONE async copy of the output block into pinned memory + one synchronisation."""
+        b = self._b
+        if self.output == "torch":
+            src = b.out.t
+        else:
+            src = b.to_host(self._obs_names + ["reward", "frames", "terminal_state"])
+        flags = src["flags"]
+        info = {
+            "player_won": (flags & 1) != 0,
+            "player_dead": (flags & 2) != 0,
+            "switch_activated": (flags & 4) != 0,
+            "death_cause_code": (flags >> 4) & 3,
+            "frames_executed": src["frames"],
+            "terminal_observation": src["terminal_state"],
+            "frame_skip_stats": {"skip_value": self.frame_skip},
+        }
+        return self._obs(src), src["reward"], (flags & 3) != 0, (flags & 8) != 0, info
 
     def step(self, actions):
         """actions: int array/tensor [N] in 0..5.  Returns (obs, reward, terminated, truncated, info) with batch dims."""
-        b = self._b
-        if isinstance(actions, torch.Tensor):
-            self._actions.copy_(actions.to(torch.uint8), non_blocking=True)
-        else:
-            self._actions.copy_(torch.as_tensor(np.asarray(actions, dtype=np.uint8)), non_blocking=True)
-        b.step(self._actions, self.frame_skip, want_terminal=True)
-        flags = b.flags
-        terminated = (flags & 3) != 0
-        truncated = (flags & 8) != 0
-        info = {
-            "player_won": self._conv((flags & 1) != 0),
-            "player_dead": self._conv((flags & 2) != 0),
-            "switch_activated": self._conv((flags & 4) != 0),
-            "death_cause_code": self._conv((flags >> 4) & 3),
-            "frames_executed": self._conv(b.frames),
-            "terminal_observation": self._conv(b.terminal_state),
-            "frame_skip_stats": {"skip_value": self.frame_skip},
-        }
-        return self._obs(), self._conv(b.reward), self._conv(terminated), self._conv(truncated), info
+        self.step_async(actions)
+        return self.step_wait()
 
     def close(self):
         self._b.close()
@@ -140,7 +169,7 @@ class NppEnvironment:
     throughput."""
 
     def __init__(self, map_data=None, custom_map_path=None, frame_skip=4, device=0, enable_visual_observations=False,
-                 truncation_limit=10000):
+                 truncation_limit=10000, fast_reset=True, enable_spatial_context=False, enable_switch_states=False):
         if map_data is None:
             if custom_map_path is None:
                 raise ValueError("NppEnvironment needs map_data or custom_map_path")
@@ -148,14 +177,20 @@ class NppEnvironment:
                 map_data = np.frombuffer(f.read(), dtype=np.uint8)
         self._v = NppVecEnvironment([map_data], 1, level_ids=[0], frame_skip=frame_skip, device=device,
                                     enable_visual_observations=enable_visual_observations,
-                                    truncation_limit=truncation_limit, output="numpy", autoreset=False)
+                                    truncation_limit=truncation_limit, output="numpy", autoreset=False,
+                                    fast_reset=fast_reset, enable_spatial_context=enable_spatial_context,
+                                    enable_switch_states=enable_switch_states)
         self.action_space = self._v.single_action_space
         self.observation_space = self._v.single_observation_space
         self.frame_skip = frame_skip
 
     @staticmethod
     def _unbatch(obs):
-        return {k: v[0] for k, v in obs.items()}
+        out = {k: v[0].copy() if isinstance(v[0], np.ndarray) else v[0] for k, v in obs.items()}
+        for k in ("player_x", "player_y", "switch_x", "switch_y", "exit_door_x", "exit_door_y"):
+            out[k] = float(out[k])
+        out["switch_activated"] = bool(out["switch_activated"])
+        return out
 
     def reset(self, seed=None, options=None):
         obs, info = self._v.reset(seed=seed, options=options)
@@ -203,27 +238,44 @@ class NPlayHeadless:
     def load_map_from_map_data(self, map_data):
         if self._b is not None:
             self._b.close()
-        self._b = NppBatch(1, device=self._device, autoreset=False)
+        self._b = NppBatch(1, device=self._device, autoreset=False, outputs=("positions",))
         self._b.load_levels([map_data])
-        self._in = torch.zeros((1, 1), dtype=torch.uint8, device=self._b.device)
+        with self._b._ctx():
+            self._in = torch.zeros((1, 1), dtype=torch.uint8, device=self._b.device)
         self.current_map_data = map_data
+        self._cache = {}
 
     def load_map(self, map_path):
         with open(map_path, "rb") as f:
             self.load_map_from_map_data(np.frombuffer(f.read(), dtype=np.uint8))
 
     def reset(self):
-        self._b.reset()
+        """Simulator.reset (nsim.py:62-76): entities re-created."""
+        self._b.reset(mode="full")
+        self._cache = {}
 
     def fast_reset(self):
-        self._b.reset()
+        """Simulator.fast_reset (nsim.py:78-140): entities reset in place (key-ordered cell lists, movers keep going)."""
+        self._b.reset(mode="fast")
+        self._cache = {}
 
     def tick(self, horizontal_input, jump_input):
-        self._in.fill_(controls_to_input_byte(horizontal_input, jump_input))
+        with self._b._ctx():
+            self._in.fill_(controls_to_input_byte(horizontal_input, jump_input))
         self._b.tick(self._in)
+        self._cache = {}
 
+    # accessors share ONE state dump / ONE observation per tick (they used to cost a device round trip each)
     def _state(self):
-        return self._b.dump_state(0, 1)
+        if "state" not in self._cache:
+            self._cache["state"] = self._b.dump_state(0, 1)
+        return self._cache["state"]
+
+    def _observed(self):
+        if "obs" not in self._cache:
+            self._b.observe()
+            self._cache["obs"] = self._b.to_host(["game_state", "action_mask", "entity_pos", "positions"])
+        return self._cache["obs"]
 
     def ninja_has_won(self):
         return int(self._state()[1][0, 0]) == 8
@@ -250,25 +302,21 @@ class NPlayHeadless:
         return bool(self._state()[1][0, 21])
 
     def get_ninja_state(self):
-        self._b.observe()
-        return [float(v) for v in self._b.game_state[0, :40].cpu().numpy()]
+        return [float(v) for v in self._observed()["game_state"][0, :40]]
 
     def get_action_mask(self):
-        self._b.observe()
-        return [bool(v) for v in self._b.action_mask[0].cpu().numpy()]
+        return [bool(v) for v in self._observed()["action_mask"][0]]
 
     def exit_switch_activated(self):
         return int(self._state()[1][0, 13]) != 1
 
     def exit_switch_position(self):
-        self._b.observe()
-        p = self._b.entity_pos[0].cpu().numpy().astype(np.float64)
-        return float(p[2] * 1056.0), float(p[3] * 600.0)
+        p = self._observed()["positions"][0]
+        return float(p[2]), float(p[3])
 
     def exit_door_position(self):
-        self._b.observe()
-        p = self._b.entity_pos[0].cpu().numpy().astype(np.float64)
-        return float(p[4] * 1056.0), float(p[5] * 600.0)
+        p = self._observed()["positions"][0]
+        return float(p[4]), float(p[5])
 
     def render(self):
         """The gray frame, numpy uint8 (600, 1056, 1), as the reference's render() returns it (nplay_headless.py:144-156)."""

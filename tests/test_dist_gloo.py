@@ -81,3 +81,88 @@ def test_world_size_2_gather_matches_single_process():
         for s in range(5):
             o.env_step(int(acts[s, e]), 4)
         assert np.array_equal(full[e, :40], o.ninja_state().astype(np.float32)), e
+
+
+def _packed_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nclone_amd.engine import OutputBlock, _ALWAYS
+
+    blk = OutputBlock(n, "cpu", set(_ALWAYS))
+    g = torch.Generator().manual_seed(100 + rank)
+    blk.t["game_state"].copy_(torch.rand((n, 41), generator=g))
+    blk.t["entity_pos"].copy_(torch.rand((n, 6), generator=g))
+    blk.t["reward"].copy_(torch.rand((n,), generator=g))
+    blk.t["frames"].copy_(torch.randint(0, 5, (n,), generator=g).to(torch.int16))
+    blk.t["action_mask"].copy_(torch.randint(0, 2, (n, 6), generator=g).to(torch.int8))
+    blk.t["flags"].copy_(torch.randint(0, 64, (n,), generator=g).to(torch.uint8))
+    packed = blk.packed()
+    gathered = torch.empty(world * packed.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered, packed)          # ONE collective for the whole observation of a rank
+    parts = blk.split_packed(gathered, world)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in parts.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_packed_observation_block_gather_world_size_2():
+    """Config 4's gather: the packed observation block (game_state, entity_positions, reward, frames, action_mask, flags)
+    of every rank moves with ONE all_gather and splits back into per-rank field views."""
+    n = 96
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        assert np.array_equal(parts["game_state"][rank], torch.rand((n, 41), generator=g).numpy())
+        assert np.array_equal(parts["entity_pos"][rank], torch.rand((n, 6), generator=g).numpy())
+        assert np.array_equal(parts["reward"][rank], torch.rand((n,), generator=g).numpy())
+        assert np.array_equal(parts["frames"][rank], torch.randint(0, 5, (n,), generator=g).to(torch.int16).numpy())
+        assert np.array_equal(parts["action_mask"][rank], torch.randint(0, 2, (n, 6), generator=g).to(torch.int8).numpy())
+        assert np.array_equal(parts["flags"][rank], torch.randint(0, 64, (n,), generator=g).to(torch.uint8).numpy())
+
+
+def test_bench_bare_invocation_starts_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` without a launcher starts 2 rank processes itself; here (no GPU) the ranks fail, which must
+    surface as a non-zero exit code and no JSON line -- not as a silent 1-rank run."""
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_two_ranks_on_one_gpu")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--preroll", "1", "--envs-per-gpu", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 launch path rehearsed on one GPU: `bench.py --gpus 2 --backend gloo --device 0` (bare invocation) runs two
+    rank processes on the HIP path and rank 0 prints n_gpus 2 with the gathered-observation figure."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--steps", "20",
+                        "--warmup", "5", "--preroll", "10", "--envs-per-gpu", "1024", "--workload", "c3mixed", "--gather-obs",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0
+    assert line["with_obs_gather"]["own_shard_roundtrip_ok"] and line["with_obs_gather"]["value"] > 0
+    assert line["config"]["preroll_steps"] == 10 and line["launch_us"]["p95"] >= line["launch_us"]["p50"]

@@ -251,7 +251,8 @@ def test_vec_env_on_zoo_levels_with_all_observations(golden):
     v = NppVecEnvironment(levels[:6], 48, level_ids=np.arange(48) % 6, enable_visual_observations=True, enable_spatial_context=True,
                           enable_switch_states=True, output="numpy")
     obs, _ = v.reset()
-    assert set(obs) == {"game_state", "action_mask", "entity_positions", "spatial_context", "switch_states", "player_frame", "global_view"}
+    assert set(obs) == {"game_state", "action_mask", "entity_positions", "spatial_context", "switch_states", "player_frame", "global_view",
+                        "player_x", "player_y", "switch_x", "switch_y", "exit_door_x", "exit_door_y", "switch_activated"}
     rng = np.random.default_rng(2)
     ended = 0
     for s in range(120):

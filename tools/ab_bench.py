@@ -16,7 +16,7 @@ from nclone_amd.levels import curriculum0_levels  # noqa: E402
 
 
 class StepOut(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("gs", "mask", "epos", "flags", "reward", "frames", "term", "sc")]
+    _fields_ = [(k, C.c_void_p) for k in ("gs", "mask", "epos", "flags", "reward", "frames", "term", "sc", "pos", "work")]
 
 
 def run(path, steps=600, warmup=60, n=8192, with_sc_field=True):
@@ -44,7 +44,7 @@ def run(path, steps=600, warmup=60, n=8192, with_sc_field=True):
     flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
     rew = torch.zeros(n, dtype=torch.float32, device="cuda")
     fr = torch.zeros(n, dtype=torch.int16, device="cuda")
-    so = StepOut(gs.data_ptr(), mask.data_ptr(), epos.data_ptr(), flags.data_ptr(), rew.data_ptr(), fr.data_ptr(), None, None)
+    so = StepOut(gs.data_ptr(), mask.data_ptr(), epos.data_ptr(), flags.data_ptr(), rew.data_ptr(), fr.data_ptr(), None, None, None, None)
     acts = torch.from_numpy(np.random.default_rng(0).integers(0, 6, size=(steps + warmup, n)).astype(np.uint8)).cuda()
     for k in range(warmup):
         L.npp_step(h, acts[k].data_ptr(), 4, C.byref(so))
