@@ -40,6 +40,7 @@ struct npp_handle_s {
     int32_t *d_trunc = nullptr;
     uint8_t *d_mask = nullptr;
     unsigned char *d_blob = nullptr;
+    uint8_t *d_canvas = nullptr;   // tile-layer coverage canvas of every level (render paths; built on first use)
     LevelHdr *d_hdr = nullptr;
     int n_words_max = 1;
     uint32_t hot_max = 0;      // largest staged-level size over the loaded set
@@ -164,6 +165,7 @@ KernelArgs base_args(npp_handle h) {
     a.trunc_limit = h->d_trunc;
     a.hdr = h->d_hdr;
     a.blob = h->d_blob;
+    a.tile_canvas = h->d_canvas;
     a.n = h->n;
     a.autoreset = (h->flags & NPP_FLAG_AUTORESET) ? 1 : 0;
     a.fast_reset = (h->flags & NPP_FLAG_FAST_RESET) ? 1 : 0;   // in-kernel auto-resets
@@ -192,6 +194,16 @@ void fill_out(KernelArgs &a, const npp_step_out *o) {
     a.out.spatial_context = o->d_spatial_context;
     a.out.positions = o->d_positions;
     a.out.work = o->d_work;
+}
+
+// The render kernels read the tile layer from a per-level coverage canvas (npp_render.hip); it is built the first time a
+// frame is asked for, so handles that never render pay neither the memory (633 600 B per level) nor the kernel.
+int ensure_canvas(npp_handle h) {
+    if (h->d_canvas) return NPP_OK;
+    const size_t bytes = (size_t)h->levels.size() * 600 * 1056 + 16;   // + 16: rows are read as aligned dword pairs
+    HIP_TRY(h, hipMalloc((void **)&h->d_canvas, bytes));
+    HIP_TRY(h, launch_tile_canvas(h->d_hdr, h->d_blob, h->d_canvas, (int)h->levels.size(), h->stream));
+    return NPP_OK;
 }
 
 // `fresh` = the entities are created for the first time since the level was assigned (the state a replay starts from);
@@ -255,7 +267,7 @@ int npp_destroy(npp_handle h) {
     DeviceGuard dg(h->device);
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
-    hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache);
+    hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
     return NPP_OK;
@@ -404,6 +416,11 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.off_mov_y0 = append(L.mov_y0.data(), 8 * L.mov_y0.size(), 8);
         H.off_edges = append(L.edges.data(), 4 * L.edges.size(), 8);
         H.off_door_tab = append(L.door_tab.data(), 4 * L.door_tab.size(), 4);
+        H.off_ent_rank = append(L.ent_rank.data(), 2 * L.ent_rank.size(), 4);
+        H.off_mov_rank = append(L.mov_rank.data(), 2 * L.mov_rank.size(), 4);
+        H.off_ent_perm = append(L.ent_perm.data(), 2 * L.ent_perm.size(), 4);
+        H.off_ent_ident = append(L.ent_ident.data(), 2 * L.ent_ident.size(), 4);
+        H.off_keep_words = append(L.ent_keep_words.data(), 4 * L.ent_keep_words.size(), 4);
         H.n_mov = (uint32_t)L.mov_meta.size();
         H.n_zdoor = (uint32_t)(L.door_tab.size() / 2);
         H.n_created = (uint32_t)L.n_created;
@@ -435,6 +452,7 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     // ---- upload (replaces the previous set)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(h->d_blob); h->d_blob = nullptr;
+    hipFree(h->d_canvas); h->d_canvas = nullptr;
     hipFree(h->d_hdr); h->d_hdr = nullptr;
     hipFree(h->d_ent); h->d_ent = nullptr;
     hipFree(h->d_zoo); h->d_zoo = nullptr;
@@ -572,6 +590,7 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_player_frame: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_player_frame: no levels loaded");
     ON_DEVICE(h);
+    if (int rc = ensure_canvas(h)) return rc;
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_render(a, d_out, (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0, h->stream));
     return NPP_OK;
@@ -617,6 +636,7 @@ int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out) {
     if (!h || !d_out || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_render_frame: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_frame: no levels loaded");
     ON_DEVICE(h);
+    if (int rc = ensure_canvas(h)) return rc;
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_full_frame(a, env0, count, d_out, h->stream));
     return NPP_OK;
@@ -626,6 +646,7 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_global_view: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_global_view: no levels loaded");
     ON_DEVICE(h);
+    if (int rc = ensure_canvas(h)) return rc;
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_global_view(a, d_out, h->stream));
     return NPP_OK;
@@ -791,7 +812,7 @@ int npp_compile_level_zoo(const double *map, int64_t n, int32_t *edges_out, doub
     }
     for (size_t d = 0; d + 1 < L.door_tab.size(); d += 2) {
         uint32_t keys[2] = {L.door_tab[d] & 0xffffu, L.door_tab[d] >> 16};
-        for (uint32_t k : keys) edges_out[((k & 0x8000u) ? NK : 0) + (int)(k & 0x7fffu)] += (int32_t)L.door_tab[d + 1];
+        for (uint32_t k : keys) edges_out[((k & 0x8000u) ? NK : 0) + (int)(k & 0x7fffu)] += (int32_t)(L.door_tab[d + 1] & 0xffu);
     }
     int nm = (int)L.mov_meta.size();
     if (movers_out) {

@@ -46,6 +46,11 @@ struct LevelHdr {
     uint32_t n_created;
     uint32_t n_balls;
     uint32_t ball_first;    // mover slot of the first death ball
+    uint32_t off_ent_rank;  // u16[n_ent] list-order number after a fast reset (entity_dic rank)
+    uint32_t off_mov_rank;  // u16[n_mov]
+    uint32_t off_ent_perm;  // u16[n_ent] CSR walk order after a fast reset
+    uint32_t off_ent_ident; // u16[n_ent] identity walk order
+    uint32_t off_keep_words;  // u32[n_words] state bits a fast reset keeps
     uint32_t pad2_;
     double db_count;
     int32_t locked_slots[5];   // CSR slots of the first five locked doors (entity_dic[6] order), -1 = none
@@ -82,6 +87,7 @@ struct KernelArgs {
     const int32_t *trunc_limit; // [n]
     const LevelHdr *hdr;  // [n_levels]
     const unsigned char *blob;
+    const uint8_t *tile_canvas;   // u8 [n_levels][600][1056]: tile-layer coverage counts (render kernels only; built lazily)
     const uint8_t *inputs;  // actions [n] (mode 0) or replay bytes [n_ticks][n] (mode 1)
     const uint8_t *reset_mask;  // reset kernel only; NULL = all
     int n;
@@ -140,5 +146,6 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
 hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
 hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *d_out, hipStream_t s);
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
+hipError_t launch_tile_canvas(const LevelHdr *d_hdr, const unsigned char *d_blob, uint8_t *d_canvas, int n_levels, hipStream_t s);
 
 }  // namespace npp

@@ -81,6 +81,7 @@ struct Nj {
     int jbuf, fbuf, wbuf, lbuf, cause, timpact;
     int jdur, fcount, ccount, pstate, fair, scf, frame, gold, doors, pcell;
     int work;   // depenetration iterations applied since the step began (npp_step_out.d_work; not part of the state)
+    int fastord;   // 1 after a Simulator.fast_reset: the cell lists are in entity_dic order (nsim.py:124-140)
 };
 
 struct Lv {
@@ -92,6 +93,7 @@ struct Lv {
     const double *ent_y;
     const uint32_t *ent_meta;
     const uint32_t *init_words;
+    const uint16_t *perm;   // CSR walk position -> slot: identity after Simulator.reset, entity_dic order after a fast reset
     uint32_t n_think, n_words;
     int obs_switch, obs_door;
     double spawn_x, spawn_y, sw_x, sw_y, door_x, door_y;
@@ -157,6 +159,7 @@ DEV void load_state(const KernelArgs &a, int e, Nj &n) {
     n.frame = D & 0xffff; n.gold = (D >> 16) & 255; n.doors = D >> 24;
     n.pcell = E & 0xffff;
     n.scvalid = (E >> 16) & 1;
+    n.fastord = (E >> 17) & 1;
     n.work = 0;
 }
 
@@ -177,7 +180,7 @@ DEV void store_state(const KernelArgs &a, int e, const Nj &n) {
     uint32_t B = (uint32_t)sat(n.jdur, 63) | (sat(n.fcount, 255) << 6) | (sat(n.ccount, 255) << 14) | (n.pstate << 22);
     uint32_t C = (uint32_t)sat(n.fair, 0xffff) | ((uint32_t)sat(n.scf, 0xffff) << 16);
     uint32_t D = (uint32_t)sat(n.frame, 0xffff) | (sat(n.gold, 255) << 16) | ((uint32_t)sat(n.doors, 255) << 24);
-    uint32_t E = (uint32_t)n.pcell | ((uint32_t)n.scvalid << 16);
+    uint32_t E = (uint32_t)n.pcell | ((uint32_t)n.scvalid << 16) | ((uint32_t)n.fastord << 17);
     a.u32[U_A * N + e] = A; a.u32[U_B * N + e] = B; a.u32[U_C * N + e] = C; a.u32[U_D * N + e] = D;
     a.u32[U_E * N + e] = E;
 }
@@ -191,6 +194,7 @@ DEV void spawn_state(const Lv &lv, Nj &n) {
     n.jdur = 0; n.fcount = 0; n.ccount = 0; n.pstate = 0; n.fair = 0; n.scf = 0; n.frame = 0; n.gold = 0; n.doors = 0;
     n.pcell = cell_coord(n.x, 43) * 25 + cell_coord(n.y, 24);
     n.scx = 0; n.scy = 0; n.scvalid = 0;   // reset_mine_overlay_cache (npp_environment.py:569-571)
+    n.fastord = 0; n.work = 0;
 }
 
 // ---- entity bits in LDS: word w of the env at w[w * stride] (stride = envs per workgroup) ----------------------------
@@ -896,7 +900,8 @@ DEV void logical_collisions(const Lv &lv, Nj &n, EntBits eb) {
     int pend0 = -1, pend1 = -1;
     for (int xc = x0; xc <= x1; xc++) {
         int i0 = lv.ent_start[xc * 25 + y0], i1 = lv.ent_start[xc * 25 + y1 + 1];
-        for (int i = i0; i < i1; i++) {
+        for (int ii = i0; ii < i1; ii++) {
+            const int i = lv.perm[ii];   // list order inside a cell: map order, or entity_dic order after a fast reset
             uint32_t meta = lv.ent_meta[i];
             uint32_t kind = meta & 15u;
             uint32_t st = ent_get(eb, i);
@@ -1393,6 +1398,34 @@ DEV void block_store_rows(const uint32_t *stage, uint32_t *dst_block, int width,
     for (int j = threadIdx.x; j < total; j += blockDim.x) dst_block[j] = stage[j];
 }
 
+// Episode reset inside the step kernel (vector-env auto-reset): Simulator.reset -- every entity re-created -- or, under
+// NPP_FLAG_FAST_RESET, Simulator.fast_reset (nsim.py:78-140), which is what NppEnvironment.reset does on the same level.
+// Executed by all lanes of the env's group on identical data (the LDS updates are idempotent).
+template <bool ZOO>
+DEV void episode_reset(const KernelArgs &a, const LevelHdr &H, Lv &lv, Zoo &z, Nj &n, EntBits eb, int nw, int r, int G) {
+    spawn_state(lv, n);
+    if (a.fast_reset) {
+        n.fastord = 1;
+        lv.perm = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_perm);
+        const uint32_t *keep = reinterpret_cast<const uint32_t *>(a.blob + H.off_keep_words);
+        for (int w = 0; w < nw; w++) {
+            const uint32_t k = keep[w];
+            eb.w[w * eb.stride] = (eb.w[w * eb.stride] & k) | (lv.init_words[w] & ~k);
+        }
+        if constexpr (ZOO) {
+            z.ent_ord = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_rank);
+            if (z.on) zoo_fast_reset_block(z, r, G);
+        }
+    } else {
+        lv.perm = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_ident);
+        for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
+        if constexpr (ZOO) {
+            z.ent_ord = z.ent_seq;
+            if (z.on) zoo_init_block(z, r, G, false);
+        }
+    }
+}
+
 // G lanes per env; EPW = 64 / G envs per wavefront; blockDim.x / 64 wavefronts per workgroup
 template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
 DEV void run(const KernelArgs &a, unsigned char *smem) {
@@ -1452,6 +1485,8 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         z.on = H.has_zoo != 0 || (ovr & (ZOO_OVR_SWITCH | ZOO_OVR_DOOR)) != 0;
         z.obs_switch = H.obs_switch; z.obs_door = H.obs_door; z.vsw_cell = -1; z.vdoor_cell = -1;
         z.ent_seq = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_seq);
+        z.ent_ord = z.ent_seq;   // chosen again once the env's state is loaded (fastord)
+        z.mov_rank = reinterpret_cast<const uint16_t *>(a.blob + H.off_mov_rank);
         z.ent_cell = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_cell);
         z.mov_meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_mov_meta);
         z.mov_x0 = reinterpret_cast<const double *>(a.blob + H.off_mov_x0);
@@ -1486,6 +1521,11 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     STAMP_INIT;
     Nj n;
     load_state(a, e, n);
+    // list order inside a cell: map order after Simulator.reset, entity_dic order after a fast reset
+    lv.perm = reinterpret_cast<const uint16_t *>(a.blob + (n.fastord ? H.off_ent_perm : H.off_ent_ident));
+    if constexpr (ZOO) {
+        if (n.fastord) z.ent_ord = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_rank);
+    }
     const int nw = (int)lv.n_words;
     if (r == 0)
         for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = a.ent_bits[(size_t)w * a.n + e];
@@ -1554,11 +1594,8 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
             if (a.out.frames) a.out.frames[o] = (uint16_t)executed;
             if (a.out.work) a.out.work[o] = (uint16_t)(n.work > 0xffff ? 0xffff : n.work);
         }
-        if (MANY && sidx + 1 < n_steps && a.autoreset && stepping && done) {   // intermediate steps reset on the spot
-            spawn_state(lv, n);
-            for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
-            if (ZOO && z.on) zoo_init_block(z, r, G, false);
-        }
+        if (MANY && sidx + 1 < n_steps && a.autoreset && stepping && done)   // intermediate steps reset on the spot
+            episode_reset<ZOO>(a, H, lv, z, n, eb, nw, r, G);
     }
 
     const bool do_reset = a.autoreset && stepping && done;
@@ -1567,11 +1604,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     // resets those envs and writes the observation every env returns.
 #pragma nounroll
     for (int pass = (a.out.terminal_state ? 0 : 1); pass < 2; pass++) {
-        if (pass == 1 && do_reset) {
-            spawn_state(lv, n);
-            for (int w = 0; w < nw; w++) eb.w[w * eb.stride] = lv.init_words[w];
-            if (ZOO && z.on) zoo_init_block(z, r, G, false);
-        }
+        if (pass == 1 && do_reset) episode_reset<ZOO>(a, H, lv, z, n, eb, nw, r, G);
         float *gdst = pass == 0 ? a.out.terminal_state : a.out.game_state;
         if (gdst) {
             if (r == 0) write_game_state(n, limit, reinterpret_cast<float *>(stage) + eib * 41);
@@ -1654,9 +1687,15 @@ __global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
     lv.spawn_x = H.spawn_x; lv.spawn_y = H.spawn_y;
     Nj n;
     spawn_state(lv, n);
+    const bool fast = a.fast_reset != 0;   // Simulator.fast_reset (nsim.py:78-140); the host never asks for it on a fresh assignment
+    n.fastord = fast ? 1 : 0;
     store_state(a, env, n);
     const uint32_t *init = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
-    for (uint32_t w = 0; w < H.n_words; w++) a.ent_bits[(size_t)w * a.n + env] = init[w];
+    const uint32_t *keep = reinterpret_cast<const uint32_t *>(a.blob + H.off_keep_words);
+    for (uint32_t w = 0; w < H.n_words; w++) {
+        const size_t at = (size_t)w * a.n + env;
+        a.ent_bits[at] = fast ? ((a.ent_bits[at] & keep[w]) | (init[w] & ~keep[w])) : init[w];
+    }
     if (a.zoo) {
         Zoo z;
         z.blk = a.zoo + (size_t)env * a.zoo_words;
@@ -1670,7 +1709,9 @@ __global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
         // never write outside this env's block, whatever the host planned (npp_load_levels checks the plan as well)
         if (z.n_door > a.zoo_doors) z.n_door = a.zoo_doors;
         if (z.n_mov > a.zoo_movers) z.n_mov = a.zoo_movers;
-        zoo_init_block(z, 0, 1, a.reset_fresh != 0);
+        z.mov_rank = reinterpret_cast<const uint16_t *>(a.blob + H.off_mov_rank);
+        if (fast) zoo_fast_reset_block(z, 0, 1);
+        else zoo_init_block(z, 0, 1, a.reset_fresh != 0);
     }
 }
 

@@ -250,7 +250,8 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
             if (vertical) { k0 = (uint32_t)(hx * EDGE_H + hy - 2) | 0x8000u; k1 = (uint32_t)(hx * EDGE_H + hy - 1) | 0x8000u; }
             else { k0 = (uint32_t)((hx - 2) * EDGE_H + hy); k1 = (uint32_t)((hx - 1) * EDGE_H + hy); }
             L.door_tab.push_back(k0 | (k1 << 16));
-            L.door_tab.push_back(type == 8 ? 0u : 1u);   // trap doors start open (entity_door_trap.py:53)
+            // initial edge counter (trap doors start open, entity_door_trap.py:53) | door class << 8 (0 locked, 1 regular, 2 trap)
+            L.door_tab.push_back((type == 8 ? 0u : 1u) | ((type == 5 ? 1u : (type == 8 ? 2u : 0u)) << 8));
             uint32_t kind = type == 5 ? EK_DOOR_REG : (type == 6 ? EK_LOCKED : EK_DOOR_TRAP);
             // 2-bit state: bit 0 active, bit 1 "closed" for regular doors (locked: closed == active, trap: closed == !active)
             raw.push_back({kind, sx, sy, cell_of(sx, sy), type == 5 ? 3u : 1u, -1, (uint32_t)type});
@@ -387,6 +388,33 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
             return a.type != b.type ? a.type < b.type : a.seq < b.seq;
         });
         for (const DicRef &d : dic) L.dic_order.push_back(d.ref);
+        // Simulator.fast_reset rebuilds every cell list while walking entity_dic: an entity's position in that walk is
+        // its list-order number afterwards
+        L.ent_rank.assign(ne, 0);
+        L.mov_rank.assign(movers.size(), 0);
+        for (size_t k = 0; k < L.dic_order.size(); k++) {
+            const uint32_t ref = L.dic_order[k];
+            if (ref & 0x80000000u) L.mov_rank[ref & 0x7fffffffu] = (uint16_t)k;
+            else L.ent_rank[ref] = (uint16_t)k;
+        }
+        // walk order of the CSR under that rule: inside a cell by rank, exit doors still last (they join their cell's
+        // list only when their switch is hit)
+        L.ent_perm.resize(ne);
+        L.ent_ident.resize(ne);
+        for (size_t s2 = 0; s2 < ne; s2++) { L.ent_perm[s2] = (uint16_t)s2; L.ent_ident[s2] = (uint16_t)s2; }
+        for (int c = 0; c < N_CELLS; c++)
+            std::stable_sort(L.ent_perm.begin() + L.ent_start[c], L.ent_perm.begin() + L.ent_start[c + 1], [&](uint16_t a, uint16_t b) {
+                const int ka = ((L.ent_meta[a] & 15u) == EK_EXIT) ? 0x10000 : L.ent_rank[a];
+                const int kb = ((L.ent_meta[b] & 15u) == EK_EXIT) ? 0x10000 : L.ent_rank[b];
+                return ka < kb;
+            });
+        // what a fast reset leaves alone: classes without reset_state() only get active = True -- a boost pad keeps
+        // "touching" (bit 1), a regular door keeps "closed" (bit 1); everything else returns to its initial bits
+        L.ent_keep_words.assign((ne + 15) / 16, 0);
+        for (size_t s2 = 0; s2 < ne; s2++) {
+            const uint32_t kind = L.ent_meta[s2] & 15u;
+            if (kind == EK_BOOST || kind == EK_DOOR_REG) L.ent_keep_words[s2 >> 4] |= 2u << ((s2 & 15) * 2);
+        }
     }
     {
         int k = 0;

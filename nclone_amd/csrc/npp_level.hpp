@@ -51,8 +51,14 @@ struct CompiledLevel {
     std::vector<uint32_t> mov_meta;    // [n_mov] MoverKind | orientation << 3 | mode << 6 | creation order << 8
     std::vector<double> mov_x0, mov_y0;  // [n_mov] position at creation (= spring / thwump origin)
     std::vector<uint32_t> edges;       // hor[EDGE_WORDS] then ver[EDGE_WORDS]: tile grid edges (bit = edge present)
-    std::vector<uint32_t> door_tab;    // [n_zdoor][2]: key0 | key1 << 16 (bit 15 of a key = vertical), initial counter
+    std::vector<uint32_t> door_tab;    // [n_zdoor][2]: key0 | key1 << 16 (bit 15 of a key = vertical); initial counter | door class << 8
     std::vector<uint32_t> dic_order;   // entity_dic walk: CSR slot, or 0x80000000 | mover index
+    // ---- Simulator.fast_reset (nsim.py:78-140): cell lists rebuilt while walking entity_dic ----
+    std::vector<uint16_t> ent_rank;    // [n_ent] position of a CSR entity in the entity_dic walk (its list-order number then)
+    std::vector<uint16_t> mov_rank;    // [n_mov] the same for movers
+    std::vector<uint16_t> ent_perm;    // [n_ent] CSR walk position -> slot when the cell lists are in entity_dic order
+    std::vector<uint16_t> ent_ident;   // [n_ent] identity (the walk order after Simulator.reset: map order)
+    std::vector<uint32_t> ent_keep_words;  // 2 bits per entity: state bits a fast reset keeps (classes without reset_state)
     int locked_slots[5] = {-1, -1, -1, -1, -1};   // CSR slots of the first five locked doors in creation order
     int n_created = 0;                 // entities created at load (first free list-order number)
     int n_balls = 0;

@@ -13,6 +13,8 @@
 // here is 4x4 supersampling, so pixels away from primitive edges are exact and edge pixels differ by a few levels.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "npp_internal.hpp"
 #include "npp_level.hpp"
 
@@ -109,10 +111,29 @@ __device__ inline int draw_cover(const Draw &d, int x, int y) {
     return cnt;
 }
 
-// Gray value of canvas pixel (x, y): background, entity layer (premultiplied gray + alpha), tile layer on top
-// (nsim_renderer.py:71-134, 176-274)
-__device__ inline int canvas_pixel(const Draw *draw, int nd, const uint8_t *tiles, int x, int y) {
-    float eg = 0.f, ea = 0.f;
+// Tile layer, precomputed: coverage count (0..16 of the 4x4 sample grid) of every canvas pixel of every loaded level,
+// u8 [n_levels][600][1056] in HBM (633 600 B per level: 324 MB for the 512-level set -- HBM is the cheap resource on this
+// part, 16 point-in-polygon tests per pixel per frame are not).  Built once by npp_load_levels.
+__global__ __launch_bounds__(256) void npp_tile_canvas_kernel(const LevelHdr *hdr, const unsigned char *blob, uint8_t *canvas) {
+    const int y = blockIdx.x, lvl = blockIdx.y;
+    const uint8_t *tiles = blob + hdr[lvl].off_tiles;
+    uint8_t *row = canvas + ((size_t)lvl * 600 + y) * 1056;
+    const int cy = y / 24;
+    for (int x = threadIdx.x; x < 1056; x += blockDim.x) {
+        const int cx = x / 24;
+        const int t = tiles[cx * 25 + cy];
+        int cnt = 0;
+        if (t == 1 || t > 33) cnt = 16;
+        else if (t)
+            for (int sy = 0; sy < 4; sy++)
+                for (int sx = 0; sx < 4; sx++)
+                    cnt += tile_inside(t, (x - cx * 24) + (sx + 0.5f) * 0.25f, (y - cy * 24) + (sy + 0.5f) * 0.25f) ? 1 : 0;
+        row[x] = (uint8_t)cnt;
+    }
+}
+
+// entity layer of one canvas pixel: premultiplied gray + alpha over the drawables in draw order (cairo operator SOURCE)
+__device__ inline void entity_layer(const Draw *draw, int nd, int x, int y, float &eg, float &ea) {
     for (int k = 0; k < nd; k++) {
         const int cnt = draw_cover(draw[k], x, y);
         if (cnt) {
@@ -121,143 +142,345 @@ __device__ inline int canvas_pixel(const Draw *draw, int nd, const uint8_t *tile
             ea = ea * (1.f - cov) + cov;
         }
     }
+}
+
+// Gray value of a canvas pixel from its entity layer and its tile coverage count: background, entity layer (premultiplied
+// gray + alpha), tile layer on top (nsim_renderer.py:71-134, 176-274)
+__device__ inline int composite(float eg, float ea, int tile_cnt) {
     int v = 202;   // int((0.299*203 + 0.587*202 + 0.114*208)) background (nsim_renderer.py:75-79)
     int a8 = (int)(ea * 255.f + 0.5f);
     if (a8 > 0) v = ((int)(eg + 0.5f) * a8 + v * (255 - a8)) >> 8;
-    int cx = x / 24, cy = y / 24;
-    int t = (cx >= 0 && cx < 44 && cy >= 0 && cy < 25) ? tiles[cx * 25 + cy] : 0;
-    if (t) {
-        int cnt = 0;
-        if (t == 1 || t > 33) cnt = 16;
-        else
-            for (int sy = 0; sy < 4; sy++)
-                for (int sx = 0; sx < 4; sx++)
-                    cnt += tile_inside(t, (x - cx * 24) + (sx + 0.5f) * 0.25f, (y - cy * 24) + (sy + 0.5f) * 0.25f) ? 1 : 0;
-        if (cnt) {
-            float cov = cnt * (1.f / 16.f);
-            int ta = (int)(cov * 255.f + 0.5f);
-            int tg = (int)(122.f * cov + 0.5f);   // luma(0x79, 0x79, 0x88) = 122, premultiplied
-            v = (tg * ta + v * (255 - ta)) >> 8;
-        }
+    if (tile_cnt) {
+        float cov = tile_cnt * (1.f / 16.f);
+        int ta = (int)(cov * 255.f + 0.5f);
+        int tg = (int)(122.f * cov + 0.5f);   // luma(0x79, 0x79, 0x88) = 122, premultiplied
+        v = (tg * ta + v * (255 - ta)) >> 8;
     }
     return v;
 }
 
+__device__ inline int canvas_pixel(const Draw *draw, int nd, const uint8_t *tile_cnt_canvas, int x, int y) {
+    float eg = 0.f, ea = 0.f;
+    entity_layer(draw, nd, x, y, eg, ea);
+    return composite(eg, ea, tile_cnt_canvas[(size_t)y * 1056 + x]);
+}
+
+// extent of a drawable for culling: centre and half extent (conservative, + 1 px of anti-aliasing)
+__device__ inline void draw_extent(const Draw &d, float &cx, float &cy, float &ex, float &ey) {
+    if (d.shape == 1) {
+        cx = 0.5f * (d.x + d.x2); cy = 0.5f * (d.y + d.y2);
+        ex = 0.5f * fabsf(d.x2 - d.x) + d.r + 1.f; ey = 0.5f * fabsf(d.y2 - d.y) + d.r + 1.f;
+    } else {
+        cx = d.x; cy = d.y; ex = d.r + 1.f; ey = d.r + 1.f;
+    }
+}
+
+// ---- the draw list, built by the whole workgroup ---------------------------------------------------------------------
 // Drawables that can touch the window [wx0, wx1] x [wy0, wy1], in the reference's draw order (later ones overwrite:
 // cairo operator SOURCE): closed door strokes (entity_renderer.py:63-97), then the active entities grouped by type
 // (:100-150: discs of RADIUS, squares of SEMI_SIDE, oriented entities as a stroke of PLATFORMWIDTH across their normal),
-// then the ninja.  Called by one thread.
-__device__ int build_draw_list(const KernelArgs &a, const LevelHdr &H, int env, double px, double py, float wx0, float wy0,
-                               float wx1, float wy1, Draw *out, int cap) {
-    int n = 0;
-    const uint32_t *meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_ent_meta);
-    const double *doors = reinterpret_cast<const double *>(a.blob + H.off_doors);
-    auto state_of = [&](int slot) { return (a.ent_bits[(size_t)(slot >> 4) * a.n + env] >> ((slot & 15) * 2)) & 3u; };
-    for (uint32_t d = 0; d < H.n_door && n < cap; d++) {
-        const int slot = (int)doors[5 * d + 4];
-        const uint32_t st = state_of(slot), kind = meta[slot] & 15u;
-        // segment.active == door closed: locked = switch not collected, regular = bit 1, trap = switch collected
-        const bool closed = kind == EK_LOCKED ? (st & 1u) != 0 : (kind == EK_DOOR_REG ? (st & 2u) != 0 : (st & 1u) == 0);
-        if (!closed) continue;
-        float x1 = (float)doors[5 * d], y1 = (float)doors[5 * d + 1], x2 = (float)doors[5 * d + 2], y2 = (float)doors[5 * d + 3];
-        if (fmaxf(x1, x2) < wx0 || fminf(x1, x2) > wx1 || fmaxf(y1, y2) < wy0 || fminf(y1, y2) > wy1) continue;
-        out[n++] = {x1, y1, 1.f, x2, y2, (float)luma(0x79, 0x79, 0x88), 1};   // DOORWIDTH 2
-    }
-    const uint16_t *order = reinterpret_cast<const uint16_t *>(a.blob + H.off_raster);
-    const double *ex = reinterpret_cast<const double *>(a.blob + H.off_ent_x);
-    const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);
-    const uint32_t *mov_meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_mov_meta);
-    const double *zb = (a.zoo && H.has_zoo) ? a.zoo + (size_t)env * a.zoo_words + ZOO_HEAD + (a.zoo_doors + 1) / 2 : nullptr;
-    const uint32_t n_draw = H.n_ent + H.n_mov;
-    for (uint32_t k = 0; k < n_draw && n < cap; k++) {
-        const uint32_t ref = order[k];
-        if (ref & 0x8000u) {   // a mover: position from the env's zoo block
-            const int m = (int)(ref & 0x7fffu);
-            if (!zb) continue;
-            const float x = (float)zb[ZOO_MOV_WORDS * m], y = (float)zb[ZOO_MOV_WORDS * m + 1];
-            if (x < wx0 || x > wx1 || y < wy0 || y > wy1) continue;
-            const uint32_t mk = mov_meta[m] & 7u;
-            if (mk == MK_DRONE) out[n++] = {x, y, 7.5f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};
-            else if (mk == MK_MINI) out[n++] = {x, y, 4.f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};
-            else if (mk == MK_BOUNCE) out[n++] = {x, y, 9.f, 0.f, 0.f, (float)luma(0xE3, 0xE3, 0xE5), 2};
-            else if (mk == MK_THWUMP) out[n++] = {x, y, 9.f, 0.f, 0.f, (float)luma(0x83, 0x83, 0x84), 2};
-            else if (mk == MK_BALL) out[n++] = {x, y, 5.f, 0.f, 0.f, (float)luma(0x15, 0xA7, 0xBD), 0};
-            else out[n++] = {x, y, 8.f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};   // shove thwump: RADIUS wins over SEMI_SIDE
-            continue;
-        }
-        const int slot = (int)ref;
-        float x = (float)ex[slot], y = (float)ey[slot];
-        if (a.zoo) {   // npp_set_entity_pos
-            const double *hd = a.zoo + (size_t)env * a.zoo_words;
-            const uint32_t ovr = reinterpret_cast<const uint32_t *>(hd + 3)[0];
-            if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)hd[4]; y = (float)hd[5]; }
-            if (slot == H.obs_door && (ovr & ZOO_OVR_DOOR)) { x = (float)hd[6]; y = (float)hd[7]; }
-        }
-        if (x < wx0 || x > wx1 || y < wy0 || y > wy1) continue;
-        const uint32_t mm = meta[slot], kind = mm & 15u, type = (mm >> 24) & 63u;
-        const uint32_t st = state_of(slot);
-        if (kind == EK_MINE) {             // always active; radius follows the state
-            out[n++] = {x, y, st == 0 ? 4.0f : (st == 1 ? 3.5f : 4.5f), 0.f, 0.f,
-                        type == 1 ? (float)luma(0x9E, 0x21, 0x26) : (float)luma(0xCE, 0x41, 0x46), 0};
-        } else if (kind == EK_EXIT) {      // always active; dark blue (0, 0, 0.5) once the switch was hit
-            out[n++] = {x, y, 12.f, 0.f, 0.f, st ? (float)luma(0, 0, 128) : (float)luma(0x83, 0x83, 0x84), 0};
-        } else if (kind == EK_DOOR_REG) {
-            continue;                      // entity_renderer.py:104-105
-        } else {
-            if ((st & 1u) == 0) continue;  // collected gold / switches are inactive and not drawn
-            if (kind == EK_GOLD) out[n++] = {x, y, 6.f, 0.f, 0.f, (float)luma(0xDB, 0xE1, 0x49), 0};
-            else if (kind == EK_SWITCH) out[n++] = {x, y, 6.f, 0.f, 0.f, (float)luma(0x6D, 0x97, 0xC3), 0};
-            else if (kind == EK_BOOST) out[n++] = {x, y, 6.f, 0.f, 0.f, (float)luma(0x66, 0x66, 0x66), 0};
-            else if (kind == EK_LAUNCH || kind == EK_ONEWAY) {
-                // _draw_oriented_entity: angle = atan2(nx, ny) + pi/2; end points (x +- sin(angle) R, y +- cos(angle) R)
-                const uint32_t o = (mm >> 8) & 7u;
-                const float dg = 0.70710678f;
-                const int sx = (o == 0 || o == 1 || o == 7) ? 1 : ((o >= 3 && o <= 5) ? -1 : 0);
-                const int sy = (o >= 1 && o <= 3) ? 1 : ((o >= 5) ? -1 : 0);
-                const float nx = (o & 1) ? sx * dg : (float)sx, ny = (o & 1) ? sy * dg : (float)sy;
-                const float R = kind == EK_LAUNCH ? 6.f : 12.f;
-                out[n++] = {x + ny * R, y - nx * R, 1.5f, x - ny * R, y + nx * R,
-                            kind == EK_LAUNCH ? (float)luma(0x86, 0x87, 0x93) : (float)luma(0x66, 0x66, 0x66), 1};   // PLATFORMWIDTH 3
-            } else out[n++] = {x, y, 5.f, 0.f, 0.f, 0.f, 0};   // locked / trap door switch: black
-        }
-    }
-    if (n < cap) out[n++] = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};   // the ninja, drawn last
-    return n;
+// then the ninja.  Thread t of the workgroup evaluates candidate t of every chunk of blockDim.x candidates (its level
+// table reads and its entity-bit read run in parallel with everybody else's); an ordered ballot / prefix compaction keeps
+// the draw order.
+struct DrawCtx {
+    const KernelArgs *a;
+    const LevelHdr *H;
+    int env;
+    float wx0, wy0, wx1, wy1;
+};
+
+__device__ inline uint32_t ent_state_of(const KernelArgs &a, int env, int slot) {
+    return (a.ent_bits[(size_t)(slot >> 4) * a.n + env] >> ((slot & 15) * 2)) & 3u;
 }
 
-__global__ __launch_bounds__(256) void npp_render_kernel(KernelArgs a, uint8_t *out, int centered) {
-    __shared__ Draw s_draw[MAX_DRAW];
-    __shared__ int s_n;
-    __shared__ int s_win[6];   // row0, col0, h, w, top_pad, left_pad
-    const int env = blockIdx.x;
-    if (env >= a.n) return;
-    const LevelHdr &H = a.hdr[a.env_level[env]];
-    const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
+__device__ inline bool door_drawable(const DrawCtx &c, uint32_t d, Draw &out) {
+    const KernelArgs &a = *c.a;
+    const LevelHdr &H = *c.H;
+    const uint32_t *meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_ent_meta);
+    const double *doors = reinterpret_cast<const double *>(a.blob + H.off_doors);
+    const int slot = (int)doors[5 * d + 4];
+    const uint32_t st = ent_state_of(a, c.env, slot), kind = meta[slot] & 15u;
+    // segment.active == door closed: locked = switch not collected, regular = bit 1, trap = switch collected
+    const bool closed = kind == EK_LOCKED ? (st & 1u) != 0 : (kind == EK_DOOR_REG ? (st & 2u) != 0 : (st & 1u) == 0);
+    if (!closed) return false;
+    float x1 = (float)doors[5 * d], y1 = (float)doors[5 * d + 1], x2 = (float)doors[5 * d + 2], y2 = (float)doors[5 * d + 3];
+    if (fmaxf(x1, x2) < c.wx0 || fminf(x1, x2) > c.wx1 || fmaxf(y1, y2) < c.wy0 || fminf(y1, y2) > c.wy1) return false;
+    out = {x1, y1, 1.f, x2, y2, (float)luma(0x79, 0x79, 0x88), 1};   // DOORWIDTH 2
+    return true;
+}
+
+__device__ inline bool entity_drawable(const DrawCtx &c, uint32_t k, Draw &out) {
+    const KernelArgs &a = *c.a;
+    const LevelHdr &H = *c.H;
+    const int env = c.env;
+    const uint16_t *order = reinterpret_cast<const uint16_t *>(a.blob + H.off_raster);
+    const uint32_t ref = order[k];
+    if (ref & 0x8000u) {   // a mover: position from the env's zoo block
+        if (!(a.zoo && H.has_zoo)) return false;
+        const double *zb = a.zoo + (size_t)env * a.zoo_words + ZOO_HEAD + (a.zoo_doors + 1) / 2;
+        const uint32_t *mov_meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_mov_meta);
+        const int m = (int)(ref & 0x7fffu);
+        const float x = (float)zb[ZOO_MOV_WORDS * m], y = (float)zb[ZOO_MOV_WORDS * m + 1];
+        if (x < c.wx0 || x > c.wx1 || y < c.wy0 || y > c.wy1) return false;
+        const uint32_t mk = mov_meta[m] & 7u;
+        if (mk == MK_DRONE) out = {x, y, 7.5f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};
+        else if (mk == MK_MINI) out = {x, y, 4.f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};
+        else if (mk == MK_BOUNCE) out = {x, y, 9.f, 0.f, 0.f, (float)luma(0xE3, 0xE3, 0xE5), 2};
+        else if (mk == MK_THWUMP) out = {x, y, 9.f, 0.f, 0.f, (float)luma(0x83, 0x83, 0x84), 2};
+        else if (mk == MK_BALL) out = {x, y, 5.f, 0.f, 0.f, (float)luma(0x15, 0xA7, 0xBD), 0};
+        else out = {x, y, 8.f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};   // shove thwump: RADIUS wins over SEMI_SIDE
+        return true;
+    }
+    const uint32_t *meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_ent_meta);
+    const double *ex = reinterpret_cast<const double *>(a.blob + H.off_ent_x);
+    const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);
+    const int slot = (int)ref;
+    float x = (float)ex[slot], y = (float)ey[slot];
+    if (a.zoo && (slot == H.obs_switch || slot == H.obs_door)) {   // npp_set_entity_pos
+        const double *hd = a.zoo + (size_t)env * a.zoo_words;
+        const uint32_t ovr = reinterpret_cast<const uint32_t *>(hd + 3)[0];
+        if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)hd[4]; y = (float)hd[5]; }
+        if (slot == H.obs_door && (ovr & ZOO_OVR_DOOR)) { x = (float)hd[6]; y = (float)hd[7]; }
+    }
+    if (x < c.wx0 || x > c.wx1 || y < c.wy0 || y > c.wy1) return false;
+    const uint32_t mm = meta[slot], kind = mm & 15u, type = (mm >> 24) & 63u;
+    const uint32_t st = ent_state_of(a, env, slot);
+    if (kind == EK_MINE) {             // always active; radius follows the state
+        out = {x, y, st == 0 ? 4.0f : (st == 1 ? 3.5f : 4.5f), 0.f, 0.f,
+               type == 1 ? (float)luma(0x9E, 0x21, 0x26) : (float)luma(0xCE, 0x41, 0x46), 0};
+        return true;
+    }
+    if (kind == EK_EXIT) {             // always active; dark blue (0, 0, 0.5) once the switch was hit
+        out = {x, y, 12.f, 0.f, 0.f, st ? (float)luma(0, 0, 128) : (float)luma(0x83, 0x83, 0x84), 0};
+        return true;
+    }
+    if (kind == EK_DOOR_REG) return false;   // entity_renderer.py:104-105
+    if ((st & 1u) == 0) return false;        // collected gold / switches are inactive and not drawn
+    if (kind == EK_GOLD) out = {x, y, 6.f, 0.f, 0.f, (float)luma(0xDB, 0xE1, 0x49), 0};
+    else if (kind == EK_SWITCH) out = {x, y, 6.f, 0.f, 0.f, (float)luma(0x6D, 0x97, 0xC3), 0};
+    else if (kind == EK_BOOST) out = {x, y, 6.f, 0.f, 0.f, (float)luma(0x66, 0x66, 0x66), 0};
+    else if (kind == EK_LAUNCH || kind == EK_ONEWAY) {
+        // _draw_oriented_entity: angle = atan2(nx, ny) + pi/2; end points (x +- sin(angle) R, y +- cos(angle) R)
+        const uint32_t o = (mm >> 8) & 7u;
+        const float dg = 0.70710678f;
+        const int sx = (o == 0 || o == 1 || o == 7) ? 1 : ((o >= 3 && o <= 5) ? -1 : 0);
+        const int sy = (o >= 1 && o <= 3) ? 1 : ((o >= 5) ? -1 : 0);
+        const float nx = (o & 1) ? sx * dg : (float)sx, ny = (o & 1) ? sy * dg : (float)sy;
+        const float R = kind == EK_LAUNCH ? 6.f : 12.f;
+        out = {x + ny * R, y - nx * R, 1.5f, x - ny * R, y + nx * R,
+               kind == EK_LAUNCH ? (float)luma(0x86, 0x87, 0x93) : (float)luma(0x66, 0x66, 0x66), 1};   // PLATFORMWIDTH 3
+    } else out = {x, y, 5.f, 0.f, 0.f, 0.f, 0};   // locked / trap door switch: black
+    return true;
+}
+
+// ordered append of one candidate per thread (thread order = list order); s_wc: one int per wavefront
+__device__ inline void append_ordered(bool keep, const Draw &d, Draw *out, int cap, int *s_n, int *s_wc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const unsigned long long bal = __ballot(keep);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wc[wave] = __popcll(bal);
+    __syncthreads();
+    int base = *s_n;
+    for (int w = 0; w < wave; w++) base += s_wc[w];
+    if (keep && base + prefix < cap) out[base + prefix] = d;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        // observation_processor.py:219-231: rows sliced with player_x, columns with player_y (axis swap)
-        double rc = centered ? py : px, cc = centered ? px : py;
-        int row0 = (int)(rc - 42), row1 = (int)(rc + 42), col0 = (int)(cc - 42), col1 = (int)(cc + 42);
-        row0 = row0 < 0 ? 0 : row0; row1 = row1 > 600 ? 600 : row1;
-        col0 = col0 < 0 ? 0 : col0; col1 = col1 > 1056 ? 1056 : col1;
-        int h = row1 - row0, w = col1 - col0;
-        h = h < 0 ? 0 : h; w = w < 0 ? 0 : w;
-        if (h > FH) h = FH;
-        if (w > FW) w = FW;
-        s_win[0] = row0; s_win[1] = col0; s_win[2] = h; s_win[3] = w;
-        s_win[4] = (FH - h) / 2; s_win[5] = (FW - w) / 2;
-        s_n = build_draw_list(a, H, env, px, py, col0 - 16.f, row0 - 16.f, col0 + w + 16.f, row0 + h + 16.f, s_draw, MAX_DRAW);
+        int t = *s_n;
+        for (int w = 0; w < nw; w++) t += s_wc[w];
+        *s_n = t < cap ? t : cap;
     }
     __syncthreads();
-    const int row0 = s_win[0], col0 = s_win[1], h = s_win[2], w = s_win[3], top = s_win[4], left = s_win[5];
+}
+
+// Called by every thread of the workgroup.  On return *s_n drawables sit in out[] (visible to all threads).
+__device__ void build_draw_list(const KernelArgs &a, const LevelHdr &H, int env, double px, double py, float wx0, float wy0,
+                                float wx1, float wy1, Draw *out, int cap, int *s_n, int *s_wc) {
+    DrawCtx c{&a, &H, env, wx0, wy0, wx1, wy1};
+    if (threadIdx.x == 0) *s_n = 0;
+    __syncthreads();
+    for (uint32_t d0 = 0; d0 < H.n_door; d0 += blockDim.x) {
+        Draw d = {};
+        const uint32_t k = d0 + threadIdx.x;
+        const bool keep = k < H.n_door && door_drawable(c, k, d);
+        append_ordered(keep, d, out, cap, s_n, s_wc);
+    }
+    const uint32_t n_draw = H.n_ent + H.n_mov;
+    for (uint32_t k0 = 0; k0 < n_draw; k0 += blockDim.x) {
+        Draw d = {};
+        const uint32_t k = k0 + threadIdx.x;
+        const bool keep = k < n_draw && entity_drawable(c, k, d);
+        append_ordered(keep, d, out, cap, s_n, s_wc);
+    }
+    if (threadIdx.x == 0 && *s_n < cap) out[(*s_n)++] = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};   // the ninja, drawn last
+    __syncthreads();
+}
+
+// The crop window of the player frame (observation_processor.py:219-231: rows sliced with player_x, columns with
+// player_y -- the reference's axis swap -- unless `centered`), clipped to the canvas, centred in the 84 x 84 output.
+struct Window { int row0, col0, h, w, top, left; };
+__device__ inline Window frame_window(double px, double py, int centered) {
+    const double rc = centered ? py : px, cc = centered ? px : py;
+    int row0 = (int)(rc - 42), row1 = (int)(rc + 42), col0 = (int)(cc - 42), col1 = (int)(cc + 42);
+    row0 = row0 < 0 ? 0 : row0; row1 = row1 > 600 ? 600 : row1;
+    col0 = col0 < 0 ? 0 : col0; col1 = col1 > 1056 ? 1056 : col1;
+    int h = row1 - row0, w = col1 - col0;
+    h = h < 0 ? 0 : h; w = w < 0 ? 0 : w;
+    if (h > FH) h = FH;
+    if (w > FW) w = FW;
+    return {row0, col0, h, w, (FH - h) / 2, (FW - w) / 2};
+}
+
+// ---- player_frame ------------------------------------------------------------------------------------------------------
+// Per env: the window's draw list (LDS), a per-output-row bit mask of the drawables whose rows it can touch (LDS), and the
+// 17 possible gray values of a pixel without entity coverage (tile coverage count -> gray; LDS).  A lane produces 4
+// horizontally adjacent pixels per pass and stores them as one dword (a wavefront writes 256 contiguous bytes).  The tile
+// layer is two aligned dword loads of the level's coverage canvas per span (the 64 envs of a level share those rows in L2).
+// Spans that no drawable touches -- almost all -- cost two loads, four table look-ups and a store.
+constexpr int PF_MASK_WORDS = (MAX_DRAW + 63) / 64;   // 3
+struct FrameLds {
+    Draw draw[MAX_DRAW];
+    unsigned long long rowmask[FH][PF_MASK_WORDS];
+    unsigned char lut[32];
+};
+
+// rows of the OUTPUT frame touched by drawable k (conservative: extent + 1 px of anti-aliasing)
+__device__ inline void frame_rowmasks(FrameLds &L, int nd, const Window &wd, int t, int nthreads) {
+    for (int r = t; r < FH; r += nthreads) {
+        unsigned long long m[PF_MASK_WORDS] = {};
+        const int fr = r - wd.top;
+        if (fr >= 0 && fr < wd.h) {
+            const float y = (float)(wd.row0 + fr);
+            for (int k = 0; k < nd; k++) {
+                float cx, cy, ex, ey;
+                draw_extent(L.draw[k], cx, cy, ex, ey);
+                if (!(cy + ey < y || cy - ey > y + 1.f)) m[k >> 6] |= 1ull << (k & 63);
+            }
+        }
+        for (int q = 0; q < PF_MASK_WORDS; q++) L.rowmask[r][q] = m[q];
+    }
+    for (int c = t; c < 17; c += nthreads) L.lut[c] = (unsigned char)composite(0.f, 0.f, c);
+}
+
+// the four pixels (r, c0 .. c0 + 3) of the output frame, packed little-endian
+__device__ inline uint32_t frame_span(const FrameLds &L, const Window &wd, const uint8_t *canvas, int r, int c0) {
+    const int fr = r - wd.top;
+    if (fr < 0 || fr >= wd.h) return 0;   // cv2.copyMakeBorder(..., value=0)
+    const int y = wd.row0 + fr;
+    const int xs = wd.col0 + c0 - wd.left;   // canvas x of the span's first pixel (pixels outside [col0, col0 + w) are padding)
+    // tile coverage of the span: two aligned dwords of the level's canvas row
+    const int xb = xs < 0 ? 0 : (xs > 1052 ? 1052 : xs);
+    const uint32_t *crow = reinterpret_cast<const uint32_t *>(canvas + (size_t)y * 1056) + (xb >> 2);
+    const unsigned long long tl = (unsigned long long)crow[0] | ((unsigned long long)crow[1] << 32);
+    const int obase = xs - (xb & ~3);
+    float eg[4] = {0.f, 0.f, 0.f, 0.f}, ea[4] = {0.f, 0.f, 0.f, 0.f};
+    bool touched = false;
+    for (int q = 0; q < PF_MASK_WORDS; q++) {
+        unsigned long long m = L.rowmask[r][q];
+        while (m) {
+            const int k = q * 64 + __builtin_ctzll(m);
+            m &= m - 1;
+            const Draw &d = L.draw[k];
+            float cx, cy, ex, ey;
+            draw_extent(d, cx, cy, ex, ey);
+            if (cx + ex < xs || cx - ex > xs + 4) continue;
+            touched = true;
+#pragma nounroll
+            for (int j = 0; j < 4; j++) {
+                const int cnt = draw_cover(d, xs + j, y);
+                if (cnt) {
+                    float cov = cnt * (1.f / 16.f);
+                    eg[j] = eg[j] * (1.f - cov) + d.gray * cov;
+                    ea[j] = ea[j] * (1.f - cov) + cov;
+                }
+            }
+        }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int fc = c0 + j - wd.left;
+        if (fc >= 0 && fc < wd.w) {
+            const int cnt = (int)((tl >> (8 * (obase + j))) & 0xffull);
+            const int v = touched ? composite(eg[j], ea[j], cnt) : (int)L.lut[cnt];
+            packed |= (uint32_t)v << (8 * j);
+        }
+    }
+    return packed;
+}
+
+// One WORKGROUP per env (default).
+__global__ __launch_bounds__(256) void npp_render_kernel(KernelArgs a, uint8_t *out, int centered) {
+    __shared__ FrameLds L;
+    __shared__ int s_n;
+    __shared__ int s_wc[4];
+    const int env = blockIdx.x;
+    if (env >= a.n) return;
+    const int lvl = a.env_level[env];
+    const LevelHdr &H = a.hdr[lvl];
+    const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
+    const Window wd = frame_window(px, py, centered);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)env * FW * FH);
+    constexpr int DW_PER_ROW = FW / 4;   // 21
+    if (wd.h == 0 || wd.w == 0) {        // the window lies outside the canvas (axis swap with player_x > 642): all padding
+        for (int q = threadIdx.x; q < DW_PER_ROW * FH; q += blockDim.x) dst[q] = 0;
+        return;
+    }
+    build_draw_list(a, H, env, px, py, wd.col0 - 16.f, wd.row0 - 16.f, wd.col0 + wd.w + 16.f, wd.row0 + wd.h + 16.f, L.draw, MAX_DRAW,
+                    &s_n, s_wc);
     const int nd = s_n;
-    const uint8_t *tiles = a.blob + H.off_tiles;
-    uint8_t *dst = out + (size_t)env * FW * FH;
-    for (int p = threadIdx.x; p < FW * FH; p += blockDim.x) {
-        int r = p / FW, c = p - r * FW;
-        int fr = r - top, fc = c - left;
-        uint8_t val = 0;   // cv2.copyMakeBorder(..., value=0)
-        if (fr >= 0 && fr < h && fc >= 0 && fc < w) val = (uint8_t)canvas_pixel(s_draw, nd, tiles, col0 + fc, row0 + fr);
-        dst[p] = val;
+    frame_rowmasks(L, nd, wd, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
+    for (int q = threadIdx.x; q < DW_PER_ROW * FH; q += blockDim.x) {
+        const int r = q / DW_PER_ROW, c0 = (q - r * DW_PER_ROW) * 4;
+        dst[q] = frame_span(L, wd, canvas, r, c0);
+    }
+}
+
+// One WAVEFRONT per env, four envs per workgroup, no workgroup barrier (a wavefront's LDS traffic is ordered, so the list it
+// compacts with ballot / prefix is its own).  A/B variant: NPP_RENDER_WAVE=1.
+__global__ __launch_bounds__(256) void npp_render_wave_kernel(KernelArgs a, uint8_t *out, int centered) {
+    __shared__ FrameLds Ls[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int env = blockIdx.x * 4 + wave;
+    if (env >= a.n) return;   // the whole wavefront leaves; nobody waits for it
+    FrameLds &L = Ls[wave];
+    const int lvl = a.env_level[env];
+    const LevelHdr &H = a.hdr[lvl];
+    const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
+    const Window wd = frame_window(px, py, centered);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)env * FW * FH);
+    constexpr int DW_PER_ROW = FW / 4;   // 21
+    if (wd.h == 0 || wd.w == 0) {
+        for (int q = lane; q < DW_PER_ROW * FH; q += 64) dst[q] = 0;
+        return;
+    }
+    int nd = 0;   // wavefront-uniform
+    {
+        DrawCtx c{&a, &H, env, wd.col0 - 16.f, wd.row0 - 16.f, wd.col0 + wd.w + 16.f, wd.row0 + wd.h + 16.f};
+        const uint32_t n_draw = H.n_ent + H.n_mov;
+        for (uint32_t k0 = 0; k0 < H.n_door + n_draw; k0 += 64) {   // doors first, then the entities in draw order
+            Draw d = {};
+            const uint32_t k = k0 + lane;
+            bool keep = false;
+            if (k < H.n_door) keep = door_drawable(c, k, d);
+            else if (k < H.n_door + n_draw) keep = entity_drawable(c, k - H.n_door, d);
+            const unsigned long long bal = __ballot(keep);
+            const int pos = nd + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && pos < MAX_DRAW - 1) L.draw[pos] = d;
+            nd += __popcll(bal);
+        }
+        nd = nd < MAX_DRAW - 1 ? nd : MAX_DRAW - 1;
+        if (lane == 0) L.draw[nd] = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};   // the ninja, drawn last
+        nd++;
+        __builtin_amdgcn_wave_barrier();
+    }
+    frame_rowmasks(L, nd, wd, lane, 64);
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
+    for (int q = lane; q < DW_PER_ROW * FH; q += 64) {
+        const int r = q / DW_PER_ROW, c0 = (q - r * DW_PER_ROW) * 4;
+        dst[q] = frame_span(L, wd, canvas, r, c0);
     }
 }
 
@@ -266,7 +489,8 @@ __global__ __launch_bounds__(256) void npp_render_kernel(KernelArgs a, uint8_t *
 // "100 / 6", "1056 / 6"), so the frame is squashed anisotropically: 600 rows -> 176 (x 3.409) and 1056 columns -> 100
 // (x 10.56).  Reproduced as is.  INTER_AREA with a non-integer factor is the area-weighted mean of the source pixels under
 // each destination pixel (OpenCV resizeArea: float weights from computeResizeAreaTab, rounded to nearest on store).
-// One workgroup per (env, output row); thread = output column.
+// One workgroup per env: the draw list of the whole canvas is built ONCE; then two output rows per pass (128 lanes each, one
+// output column per lane), each half first compacting the drawables that touch its rows' source band into an LDS index list.
 constexpr int GV_ROWS = 176, GV_COLS = 100, GV_DRAW = 224;
 
 // OpenCV computeResizeAreaTab for one destination index: source range [s1 - (head > 0), s2 + (tail > 0)) with weights
@@ -282,75 +506,86 @@ __device__ inline void area_tab(int d, float scale, int ssize, int &s1, int &s2,
     wtail = (f2 - s2 > 1e-3f) ? fminf(fminf(f2 - s2, 1.f), cell) / cell : 0.f;
 }
 
-__global__ __launch_bounds__(128) void npp_global_view_kernel(KernelArgs a, uint8_t *out) {
+__global__ __launch_bounds__(256) void npp_global_view_kernel(KernelArgs a, uint8_t *out) {
     __shared__ Draw s_draw[GV_DRAW];
     __shared__ int s_n;
-    const int env = blockIdx.x / GV_ROWS, r = blockIdx.x - env * GV_ROWS;
+    __shared__ int s_wc[4];
+    __shared__ unsigned char s_row[2][GV_DRAW];   // per half: indices of the drawables touching its source band, in draw order
+    __shared__ int s_rown[2];
+    const int env = blockIdx.x;
     if (env >= a.n) return;
-    const LevelHdr &H = a.hdr[a.env_level[env]];
+    const int lvl = a.env_level[env];
+    const LevelHdr &H = a.hdr[lvl];
     const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
+    build_draw_list(a, H, env, px, py, -16.f, -16.f, 1056.f + 16.f, 600.f + 16.f, s_draw, GV_DRAW, &s_n, s_wc);
+    const int nd = s_n;
+    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
     const float sy = 600.f / GV_ROWS, sx = 1056.f / GV_COLS;
-    int y1, y2;
-    float wyh, wym, wyt;
-    area_tab(r, sy, 600, y1, y2, wyh, wym, wyt);
-    const int ya = wyh > 0.f ? y1 - 1 : y1, yb = wyt > 0.f ? y2 + 1 : y2;   // canvas rows [ya, yb)
-    if (threadIdx.x == 0)
-        s_n = build_draw_list(a, H, env, px, py, -16.f, ya - 16.f, 1056.f + 16.f, yb + 16.f, s_draw, GV_DRAW);
-    __syncthreads();
-    const int c = threadIdx.x;
-    if (c >= GV_COLS) return;
-    int x1, x2;
-    float wxh, wxm, wxt;
-    area_tab(c, sx, 1056, x1, x2, wxh, wxm, wxt);
+    const int half = threadIdx.x >> 7, c = threadIdx.x & 127, hw = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
+    int x1 = 0, x2 = 0;
+    float wxh = 0.f, wxm = 0.f, wxt = 0.f;
+    if (c < GV_COLS) area_tab(c, sx, 1056, x1, x2, wxh, wxm, wxt);
     const int xa = wxh > 0.f ? x1 - 1 : x1, xb = wxt > 0.f ? x2 + 1 : x2;
-    const uint8_t *tiles = a.blob + H.off_tiles;
-    // drawables near this destination pixel's source rectangle
-    int near[24], nn = 0;
-    for (int k = 0; k < s_n; k++) {
-        const Draw &d = s_draw[k];
-        float ext = d.shape == 1 ? 0.5f * sqrtf((d.x2 - d.x) * (d.x2 - d.x) + (d.y2 - d.y) * (d.y2 - d.y)) + d.r : d.r;
-        ext = d.shape == 2 ? ext * 1.4143f : ext;
-        float cx = d.shape == 1 ? 0.5f * (d.x + d.x2) : d.x, cy = d.shape == 1 ? 0.5f * (d.y + d.y2) : d.y;
-        if (cx + ext + 1.f >= xa && cx - ext - 1.f <= xb && cy + ext + 1.f >= ya && cy - ext - 1.f <= yb && nn < 24) near[nn++] = k;
-    }
-    float acc = 0.f;
-    for (int y = ya; y < yb; y++) {
-        const float wy = (y < y1) ? wyh : (y < y2 ? wym : wyt);
-        for (int x = xa; x < xb; x++) {
-            const float wx = (x < x1) ? wxh : (x < x2 ? wxm : wxt);
-            float eg = 0.f, ea = 0.f;
-            for (int q = 0; q < nn; q++) {
-                const Draw &d = s_draw[near[q]];
-                const int cnt = draw_cover(d, x, y);
-                if (cnt) {
-                    float cov = cnt * (1.f / 16.f);
-                    eg = eg * (1.f - cov) + d.gray * cov;
-                    ea = ea * (1.f - cov) + cov;
-                }
+    for (int r0 = 0; r0 < GV_ROWS; r0 += 2) {
+        const int r = r0 + half;
+        int y1, y2;
+        float wyh, wym, wyt;
+        area_tab(r, sy, 600, y1, y2, wyh, wym, wyt);
+        const int ya = wyh > 0.f ? y1 - 1 : y1, yb = wyt > 0.f ? y2 + 1 : y2;   // canvas rows [ya, yb)
+        // ordered compaction of the band's drawables (each half = 2 wavefronts = 128 candidates per pass)
+        if (c == 0) s_rown[half] = 0;
+        __syncthreads();
+        for (int k0 = 0; k0 < nd; k0 += 128) {
+            const int k = k0 + c;
+            bool keep = false;
+            if (k < nd) {
+                float cx, cy, ex, ey;
+                draw_extent(s_draw[k], cx, cy, ex, ey);
+                keep = cy + ey >= ya && cy - ey <= yb;
             }
-            int v = 202;
-            int a8 = (int)(ea * 255.f + 0.5f);
-            if (a8 > 0) v = ((int)(eg + 0.5f) * a8 + v * (255 - a8)) >> 8;
-            const int cx = x / 24, cy = y / 24;
-            const int t = tiles[cx * 25 + cy];
-            if (t) {
-                int cnt = 0;
-                if (t == 1 || t > 33) cnt = 16;
-                else
-                    for (int qy = 0; qy < 4; qy++)
-                        for (int qx = 0; qx < 4; qx++)
-                            cnt += tile_inside(t, (x - cx * 24) + (qx + 0.5f) * 0.25f, (y - cy * 24) + (qy + 0.5f) * 0.25f) ? 1 : 0;
-                if (cnt) {
-                    float cov = cnt * (1.f / 16.f);
-                    int ta = (int)(cov * 255.f + 0.5f);
-                    int tg = (int)(122.f * cov + 0.5f);
-                    v = (tg * ta + v * (255 - ta)) >> 8;
-                }
-            }
-            acc += wy * wx * (float)v;
+            const unsigned long long bal = __ballot(keep);
+            const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wc[half * 2 + hw] = __popcll(bal);
+            __syncthreads();
+            const int base = s_rown[half] + (hw ? s_wc[half * 2] : 0);
+            if (keep) s_row[half][base + prefix] = (unsigned char)k;
+            __syncthreads();
+            if (c == 0) s_rown[half] += s_wc[half * 2] + s_wc[half * 2 + 1];
+            __syncthreads();
         }
+        const int nrow = s_rown[half];
+        if (c < GV_COLS) {
+            // drawables near this destination pixel's source rectangle
+            int near[24], nn = 0;
+            for (int q = 0; q < nrow; q++) {
+                const int k = s_row[half][q];
+                float cx, cy, ex, ey;
+                draw_extent(s_draw[k], cx, cy, ex, ey);
+                if (cx + ex >= xa && cx - ex <= xb && nn < 24) near[nn++] = k;
+            }
+            float acc = 0.f;
+            for (int y = ya; y < yb; y++) {
+                const float wy = (y < y1) ? wyh : (y < y2 ? wym : wyt);
+                const uint8_t *crow = canvas + (size_t)y * 1056;
+                for (int x = xa; x < xb; x++) {
+                    const float wx = (x < x1) ? wxh : (x < x2 ? wxm : wxt);
+                    float eg = 0.f, ea = 0.f;
+                    for (int q = 0; q < nn; q++) {
+                        const Draw &d = s_draw[near[q]];
+                        const int cnt = draw_cover(d, x, y);
+                        if (cnt) {
+                            float cov = cnt * (1.f / 16.f);
+                            eg = eg * (1.f - cov) + d.gray * cov;
+                            ea = ea * (1.f - cov) + cov;
+                        }
+                    }
+                    acc += wy * wx * (float)composite(eg, ea, crow[x]);
+                }
+            }
+            out[((size_t)env * GV_ROWS + r) * GV_COLS + c] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
+        }
+        __syncthreads();
     }
-    out[((size_t)env * GV_ROWS + r) * GV_COLS + c] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
 }
 
 // The whole gray canvas of one env range (NPlayHeadless.render() in grayscale mode: nsim_renderer.py:71-134, array of shape
@@ -358,16 +593,17 @@ __global__ __launch_bounds__(128) void npp_global_view_kernel(KernelArgs a, uint
 __global__ __launch_bounds__(256) void npp_full_frame_kernel(KernelArgs a, int env0, uint8_t *out) {
     __shared__ Draw s_draw[GV_DRAW];
     __shared__ int s_n;
+    __shared__ int s_wc[4];
     const int e = blockIdx.x / 600, y = blockIdx.x - e * 600;
     const int env = env0 + e;
     if (env >= a.n) return;
-    const LevelHdr &H = a.hdr[a.env_level[env]];
+    const int lvl = a.env_level[env];
+    const LevelHdr &H = a.hdr[lvl];
     const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
-    if (threadIdx.x == 0) s_n = build_draw_list(a, H, env, px, py, -16.f, y - 16.f, 1056.f + 16.f, y + 1 + 16.f, s_draw, GV_DRAW);
-    __syncthreads();
-    const uint8_t *tiles = a.blob + H.off_tiles;
+    build_draw_list(a, H, env, px, py, -16.f, y - 16.f, 1056.f + 16.f, y + 1 + 16.f, s_draw, GV_DRAW, &s_n, s_wc);
+    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
     uint8_t *row = out + ((size_t)e * 600 + y) * 1056;
-    for (int x = threadIdx.x; x < 1056; x += blockDim.x) row[x] = (uint8_t)canvas_pixel(s_draw, s_n, tiles, x, y);
+    for (int x = threadIdx.x; x < 1056; x += blockDim.x) row[x] = (uint8_t)canvas_pixel(s_draw, s_n, canvas, x, y);
 }
 
 // switch_states (gym_environment/npp_environment.py:1782-1847): up to MAX_LOCKED_DOORS = 5 locked doors x [switch x, switch y,
@@ -407,12 +643,19 @@ hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s
 }
 
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s) {
-    hipLaunchKernelGGL(npp_render_kernel, dim3(a.n), dim3(256), 0, s, a, d_out, centered);
+    static const bool wave = std::getenv("NPP_RENDER_WAVE") != nullptr;   // A/B aid: the one-wavefront-per-env variant
+    if (wave) hipLaunchKernelGGL(npp_render_wave_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, a, d_out, centered);
+    else hipLaunchKernelGGL(npp_render_kernel, dim3(a.n), dim3(256), 0, s, a, d_out, centered);
     return hipGetLastError();
 }
 
 hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s) {
-    hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n * GV_ROWS), dim3(128), 0, s, a, d_out);
+    hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n), dim3(256), 0, s, a, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_canvas(const LevelHdr *d_hdr, const unsigned char *d_blob, uint8_t *d_canvas, int n_levels, hipStream_t s) {
+    hipLaunchKernelGGL(npp_tile_canvas_kernel, dim3(600, n_levels), dim3(256), 0, s, d_hdr, d_blob, d_canvas);
     return hipGetLastError();
 }
 

@@ -21,7 +21,9 @@
 struct Zoo {
     double *blk;              // LDS: this env's zoo block (layout: ZOO_HEAD in npp_internal.hpp)
     uint32_t *edges;          // LDS: hor[EDGE_WORDS_D] | ver[EDGE_WORDS_D] tile grid edges of this env's level
-    const uint16_t *ent_seq;
+    const uint16_t *ent_seq;  // creation order of a CSR entity
+    const uint16_t *ent_ord;  // its list-order number inside a cell: creation order, or the entity_dic rank after a fast reset
+    const uint16_t *mov_rank; // entity_dic rank of a mover (its list-order number after a fast reset)
     const uint16_t *ent_cell;
     const uint32_t *mov_meta;
     const double *mov_x0;
@@ -67,7 +69,7 @@ DEV void zoo_init_block(const Zoo &z, int r, int G, bool fresh) {
         if (fresh) { zoo_ovr_w(z)[0] = 0; z.blk[4] = 0; z.blk[5] = 0; z.blk[6] = 0; z.blk[7] = 0; }   // new level: nothing moved
         zoo_ovr_w(z)[1] = 0;
     }
-    for (int d = r; d < z.n_door; d += G) *zoo_door(z, d) = door_pack((int)z.door_tab[2 * d + 1], 0);
+    for (int d = r; d < z.n_door; d += G) *zoo_door(z, d) = door_pack((int)(z.door_tab[2 * d + 1] & 0xffu), 0);
     for (int m = r; m < z.n_mov; m += G) {
         const uint32_t meta = z.mov_meta[m];
         const uint32_t kind = meta & 7u, orient = (meta >> 3) & 7u;
@@ -82,6 +84,22 @@ DEV void zoo_init_block(const Zoo &z, int r, int G, bool fresh) {
         w[0] = (uint32_t)pos_cell(x, y) | (bits << 11) | (kind << 17) | (orient << 20) | (((meta >> 6) & 3u) << 23);
         w[1] = meta >> 8;
     }
+}
+
+// Simulator.fast_reset (nsim.py:78-140) on the zoo block: nothing is re-created.  Locked and trap doors return to their
+// initial edge counter (reset_state -> change_state), regular doors keep counter and timer; movers keep position, speed,
+// state and cell and get their entity_dic rank as list-order number (the cell lists are refilled while walking entity_dic);
+// the ninja's launch-pad boost direction is not touched by Ninja.reset_state; the "first creation" flag stays.
+DEV void zoo_fast_reset_block(const Zoo &z, int r, int G) {
+    if (r == 0) {
+        zoo_head_w(z)[0] = (uint32_t)z.n_created + 1u;
+        zoo_ovr_w(z)[1] = 0;   // the exit door leaves the grid until its switch is hit again
+    }
+    for (int d = r; d < z.n_door; d += G) {
+        const uint32_t t = z.door_tab[2 * d + 1];
+        if (((t >> 8) & 3u) != 1u) *zoo_door(z, d) = door_pack((int)(t & 0xffu), 0);   // 1 = regular door: untouched
+    }
+    for (int m = r; m < z.n_mov; m += G) zoo_mov_w(z, m)[1] = z.mov_rank[m];
 }
 
 // ---- grid edges (physics.py:16-18, 210-235; entity_door_base.py:78-89, 99-108) ------------------------------------
@@ -686,7 +704,7 @@ DEV void collide_vs_objects(const Lv &lv, const Zoo &z, int r, Nj &n, ZTick &zt,
         for (int i = i0; i < i1; i++) {
             const uint32_t meta = lv.ent_meta[i];
             if ((meta & 15u) != EK_ONEWAY) continue;
-            const int key = zoo_key(z.ent_cell[i], z.ent_seq[i]);
+            const int key = zoo_key(z.ent_cell[i], z.ent_ord[i]);
             while (nm >= 0 && nk < key) {
                 mover_physical(z, nm, n, zt, fnsx, fnsy, cnsx, cnsy);
                 const int last = nk;
@@ -797,7 +815,7 @@ DEV double logical_collisions_zoo(const Lv &lv, const Zoo &z, int r, Nj &n, EntB
             if ((i == z.obs_switch && z.vsw_cell >= 0) || (i == z.obs_door && z.vdoor_cell >= 0)) continue;   // lives elsewhere now
             if (nm >= 0) {
                 // the exit door was appended to its cell's list when its switch was hit: it carries that number
-                const int key = zoo_key(z.ent_cell[i], (i == z.obs_door && zoo_ovr_w(z)[1] != 0) ? zoo_ovr_w(z)[1] : (uint32_t)z.ent_seq[i]);
+                const int key = zoo_key(z.ent_cell[i], (i == z.obs_door && zoo_ovr_w(z)[1] != 0) ? zoo_ovr_w(z)[1] : (uint32_t)z.ent_ord[i]);
                 while (nm >= 0 && nk < key) {
                     visit(nm);
                     const int last = nk;

@@ -670,6 +670,45 @@ void osim_reset(OSim *S)
     apply_overrides(S);
 }
 
+/* Simulator.fast_reset (nsim.py:78-140): the reset NppEnvironment.reset uses for same-level resets
+ * (npp_environment.py:541-557).  Nothing is re-created: the ninja is reset in place (ninja.py:1288-1394), the per-cell lists
+ * are cleared and refilled while walking entity_dic (keys ascending, creation order inside a key: nsim.py:124-140), every
+ * entity whose class defines reset_state() goes back to its initial position / state (toggle mine, gold, exit door, exit
+ * switch, locked door, trap door), every other entity only gets active = True and keeps position, cell, speed, state,
+ * door counters and timers (drones, thwumps, bounce blocks, death balls, shove thwumps, boost pads, regular doors, launch
+ * pads, one-ways).  The grid edges are NOT restored from the tiles: doors fix theirs through change_state. */
+void osim_fast_reset(OSim *S)
+{
+    S->frame = 0;
+    S->sc_valid = 0;   /* reset_mine_overlay_cache(): npp_environment.py:569-571 */
+    S->ncached = 0;
+    {   /* Ninja.reset_state keeps xlp / ylp_boost_normalized (not listed in ninja.py:1288-1394) */
+        double lx = S->nj.xlp_boost_normalized, ly = S->nj.ylp_boost_normalized;
+        ninja_init(S);
+        S->nj.xlp_boost_normalized = lx; S->nj.ylp_boost_normalized = ly;
+    }
+    for (int x = 0; x < GW; x++)
+        for (int y = 0; y < GH; y++) S->grid[x][y].n = 0;
+    for (int i = 0; i < S->ndic; i++) {
+        Entity *e = S->dic_order[i];
+        switch (e->kind) {
+        case K_MINE: case K_GOLD: case K_EXIT: case K_SWITCH: case K_LOCKED: case K_DOOR_TRAP:
+            e->x = e->x0; e->y = e->y0; e->cx = e->cx0; e->cy = e->cy0;
+            e->active = 1;
+            if (e->kind == K_MINE) mine_set_state(e, e->init_state);
+            if (e->kind == K_EXIT) e->switch_hit = 0;
+            if (e->kind == K_LOCKED && !e->closed) { e->closed = 1; door_edges_add(S, e, 1); }     /* entity_door_locked.py:69-77 */
+            if (e->kind == K_DOOR_TRAP && e->closed) { e->closed = 0; door_edges_add(S, e, -1); }  /* entity_door_trap.py:69-77 */
+            break;
+        default:
+            e->active = 1;
+            break;
+        }
+        if (e->kind != K_EXIT) elist_push(&S->grid[e->cx][e->cy], e);
+    }
+    apply_overrides(S);
+}
+
 OSim *osim_create(void) { return calloc(1, sizeof(OSim)); }
 
 static void free_level(OSim *S)
@@ -2229,6 +2268,21 @@ int osim_entity_states(const OSim *S, int *out, int max)
     for (int i = 0; i < S->nents && r < max; i++) {
         const Entity *e = &S->ents[i];
         out[r++] = e->kind == K_MINE ? e->state : (e->kind == K_EXIT ? e->switch_hit : e->active);
+    }
+    return r;
+}
+
+/* per-entity state in entity_dic order (tests/golden/make_golden_fast.py ent_states): mines -> state, exit door ->
+ * switch_hit, doors -> closed + 2 * active, others -> active */
+int osim_entity_states_dic(const OSim *S, int *out, int max)
+{
+    int r = 0;
+    for (int i = 0; i < S->ndic && r < max; i++) {
+        const Entity *e = S->dic_order[i];
+        if (e->kind == K_MINE) out[r++] = e->state;
+        else if (e->kind == K_EXIT) out[r++] = e->switch_hit;
+        else if (e->kind == K_DOOR_REG || e->kind == K_LOCKED || e->kind == K_DOOR_TRAP) out[r++] = e->closed + 2 * e->active;
+        else out[r++] = e->active;
     }
     return r;
 }

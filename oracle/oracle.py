@@ -48,6 +48,9 @@ def _lib(variant):
     lib.osim_load.argtypes = [P, C.POINTER(C.c_double), C.c_int]
     lib.osim_load.restype = C.c_int
     lib.osim_reset.argtypes = [P]
+    lib.osim_fast_reset.argtypes = [P]
+    lib.osim_entity_states_dic.argtypes = [P, C.POINTER(C.c_int), C.c_int]
+    lib.osim_entity_states_dic.restype = C.c_int
     lib.osim_tick.argtypes = [P, C.c_int, C.c_int]
     lib.osim_get_ninja_state.argtypes = [P, C.POINTER(C.c_double)]
     lib.osim_spatial_context.argtypes = [P, C.POINTER(C.c_float)]
@@ -99,7 +102,17 @@ class Oracle:
         return r
 
     def reset(self):
+        """Simulator.reset (nsim.py:62-76)."""
         self.lib.osim_reset(self.h)
+
+    def fast_reset(self):
+        """Simulator.fast_reset (nsim.py:78-140)."""
+        self.lib.osim_fast_reset(self.h)
+
+    def entity_states_dic(self):
+        buf = np.zeros(4096, dtype=np.int32)
+        n = self.lib.osim_entity_states_dic(self.h, buf.ctypes.data_as(C.POINTER(C.c_int)), len(buf))
+        return buf[:n].copy()
 
     def tick(self, hor, jump):
         self.lib.osim_tick(self.h, int(hor), int(jump))

@@ -263,3 +263,37 @@ def test_vec_env_on_zoo_levels_with_all_observations(golden):
     assert np.isfinite(obs["game_state"]).all() and np.abs(obs["game_state"]).max() <= 1.0 + 1e-6
     assert ended > 0 and set(np.unique(info["death_cause_code"])) <= {0, 1, 2}
     v.close()
+
+
+def test_player_frame_config3_full_size(golden):
+    """Config 3 at size: 8192 envs on the mine level set, frames rendered after every step of a random rollout with
+    auto-reset.  Replica envs (same level, same actions) must produce identical frames whatever workgroup renders them; a
+    sample of frames is compared with the numpy restatement (same tolerance as the small tests; parity of the raster
+    itself is unpinned -- no cairo / cv2 reference frame exists); frames are real pictures (not constant)."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import mine_levels
+    from tests.raster_ref import player_frame
+
+    levels, _ = mine_levels()
+    N = 8192
+    lvl = (np.arange(N) // 64) % len(levels)
+    steps = 40
+    acts_np = np.random.default_rng(1).integers(0, 6, size=(steps, N)).astype(np.uint8).reshape(steps, N // 64, 64)
+    acts_np[:, :, 32:] = acts_np[:, :, :32]
+    acts = torch.from_numpy(acts_np.reshape(steps, N)).cuda()
+    b = NppBatch(N, autoreset=True, outputs=("player_frame",))
+    b.load_levels(levels)
+    b.assign_levels(lvl)
+    for s in range(steps):
+        b.step(acts[s])
+        b.render_player_frame()
+    frames = b.out.t["player_frame"].cpu().numpy()[..., 0]
+    fb = frames.reshape(N // 64, 64, 84, 84)
+    assert np.array_equal(fb[:, :32], fb[:, 32:])
+    # with the reference's axis swap a player at x > 642 gets an all-padding frame: not every frame is a picture
+    assert (frames.reshape(N, -1).std(axis=1) > 1).mean() > 0.3
+    f, _ = b.dump_state()
+    for e in np.random.default_rng(3).choice(N, size=48, replace=False):
+        ref, edge = player_frame(levels[lvl[e]], b.dump_entities(int(e)), f[e, 0], f[e, 1], centered=False)
+        d = np.abs(frames[e].astype(np.int64) - ref.astype(np.int64))
+        assert len(np.argwhere((d > 0) & ~edge)) == 0 and d.max(initial=0) <= 64 and d.mean() < 2.0, e

@@ -258,3 +258,102 @@ def test_device_guard_and_reset_modes():
     f, i = b.dump_state()
     assert (i[:, 22] == 0).all()
     b.close()
+
+
+def test_fast_reset_vs_reference_fixtures(golden):
+    """Simulator.fast_reset (nsim.py:78-140) on the device against the reference's own runs (tests/golden/fast.npz: 58 rollouts
+    on mine / locked-door / mine-soup levels and on every zoo map, resets forced mid-flight, fast and full resets mixed):
+    every step's final ninja state within the north-star bars (f32 positions within 1e-5, discrete state identical), the
+    entity checksum (positions, speeds and state codes of every entity: movers that keep going across a fast reset),
+    game_state and action mask."""
+    from nclone_amd.engine import NppBatch
+
+    g = golden.z("fast")
+    names = golden.names("fast")
+    n = len(names)
+    levels = [g["m%d" % r] for r in range(n)]
+    b = NppBatch(n, autoreset=False)
+    b.load_levels(levels)
+    b.assign_levels(np.arange(n))
+    steps = [len(g["a%d" % r]) for r in range(n)]
+    acts = np.zeros((max(steps), n), dtype=np.uint8)
+    for r in range(n):
+        acts[:steps[r], r] = g["a%d" % r]
+    d_acts = torch.from_numpy(acts).cuda()
+    row = np.zeros(n, dtype=np.int64)
+    checked = 0
+    for s in range(max(steps)):
+        b.step(d_acts[s])
+        f, i = b.dump_state()
+        cs = b.entity_checksum()
+        gs = b.game_state.cpu().numpy()
+        mk = b.action_mask.cpu().numpy()
+        fr = b.frames.cpu().numpy()
+        full = np.zeros(n, dtype=np.uint8)
+        fast = np.zeros(n, dtype=np.uint8)
+        for r in range(n):
+            if s >= steps[r]:
+                continue
+            ex, term, frame, mode = (int(v) for v in g["s%d" % r][s])
+            assert int(fr[r]) == ex, (names[r], s)
+            row[r] += ex
+            T, D, E = g["t%d" % r][row[r] - 1], g["d%d" % r][row[r] - 1], g["e%d" % r][row[r] - 1]
+            assert np.abs(f[r, :2].astype(np.float32) - T[:2].astype(np.float32)).max() <= 1e-5, (names[r], s, f[r, :4], T)
+            assert np.array_equal(f[r, :4], T), (names[r], s, f[r, :4], T)      # in fact the same bits on this corpus
+            assert np.array_equal(i[r, :20].clip(0, 255), D), (names[r], s)
+            assert np.allclose(cs[r], E, rtol=0, atol=1e-9) and np.array_equal(cs[r, 4:], E[4:]), (names[r], s, cs[r], E)
+            assert np.abs(gs[r, :40] - g["g%d" % r][s]).max() <= 2e-6, (names[r], s)
+            assert int(sum(int(v) << k for k, v in enumerate(mk[r]))) == int(g["k%d" % r][s]), (names[r], s)
+            full[r] = mode == 1
+            fast[r] = mode == 2
+            checked += 1
+        if full.any():
+            b.reset(full, mode="full")
+        if fast.any():
+            b.reset(fast, mode="fast")
+    assert checked == sum(steps)
+
+
+def test_fast_reset_autoreset_vs_oracle(oracle_mod):
+    """In-kernel auto-reset under NPP_FLAG_FAST_RESET (what NppVecEnvironment uses by default) on zoo, mine and door levels:
+    bit-identical to the oracle stepping the same actions with fast_reset() after every terminal step; and different from
+    the full-reset handle on the zoo levels (movers keep going)."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import door_levels, mine_levels, zoo_levels
+
+    levels = zoo_levels()[0][:10] + mine_levels()[0][:6] + door_levels()[0][:4]
+    n = 4 * len(levels)
+    lvl = np.arange(n) % len(levels)
+    steps = 160
+    acts = np.random.default_rng(17).integers(0, 6, size=(steps, n)).astype(np.uint8)
+    d_acts = torch.from_numpy(acts).cuda()
+
+    def run(fast):
+        b = NppBatch(n, autoreset=True, fast_reset=fast)
+        b.load_levels(levels)
+        b.assign_levels(lvl)
+        b.set_truncation_limit(150)          # forces resets mid-flight on top of deaths
+        for s in range(steps):
+            b.step(d_acts[s])
+        return b
+
+    bf = run(True)
+    f, i = bf.dump_state()
+    cs = bf.entity_checksum()
+    resets = 0
+    for e in range(n):
+        o = oracle_mod.Oracle("mul")
+        o.load(levels[lvl[e]])
+        for s in range(steps):
+            k, fl = o.env_step(int(acts[s, e]), 4)
+            if fl or o.frame >= 150:
+                o.fast_reset()
+                resets += 1
+        of, od = o.core()
+        assert np.array_equal(f[e], of), (e, lvl[e], f[e], of)
+        assert np.array_equal(i[e, :22], od[:22]), (e, lvl[e])
+        assert np.array_equal(cs[e], o.entity_checksum()), (e, lvl[e], cs[e], o.entity_checksum())
+    assert resets > n
+    bs = run(False)
+    cs2 = bs.entity_checksum()
+    assert not np.array_equal(cs[lvl < 10], cs2[lvl < 10])

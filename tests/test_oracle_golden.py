@@ -297,3 +297,41 @@ def test_oracle_c3_mixed_rollouts_and_tables(golden, oracle_mod):
                     o.reset()
             ticks += row
     assert ticks == 2 * 19173
+
+
+def test_oracle_fast_reset_rollouts(golden, oracle_mod):
+    """Simulator.fast_reset (nsim.py:78-140) between episodes, mixed with full resets, on mine / locked-door levels and on
+    every zoo map (tests/golden/make_golden_fast.py ran the reference): ninja trajectory, discrete state, entity checksum at
+    every tick and the per-entity states at every step, bit for bit."""
+    g = golden.z("fast")
+    names = golden.names("fast")
+    assert len(names) == 58
+    ticks = 0
+    for r in range(len(names)):
+        o = oracle_mod.Oracle("pow")
+        assert o.load(g["m%d" % r]) == 0
+        T, D, E, S, Q, G, K = (g["%s%d" % (k, r)] for k in "tdesqgk")
+        row = 0
+        for s, a in enumerate(g["a%d" % r]):
+            h, j = oracle_mod.ACTIONS[int(a)]
+            ex, term, frame, mode = (int(v) for v in S[s])
+            for _ in range(ex):
+                o.tick(h, j)
+                f, d = o.core()
+                assert np.array_equal(f[:4], T[row]), (names[r], s, row)
+                assert np.array_equal(d[:20].clip(0, 255), D[row]), (names[r], s, row)
+                assert np.array_equal(o.entity_checksum(), E[row]), (names[r], s, row, o.entity_checksum(), E[row])
+                row += 1
+            assert (1 if d[0] == 8 else (2 if d[0] in (6, 7) else 0)) == term
+            assert np.array_equal(o.entity_states_dic(), Q[s]), (names[r], s)
+            assert np.array_equal(o.ninja_state().astype(np.float32), G[s]), (names[r], s)
+            assert o.action_mask() == K[s]
+            if mode == 1:
+                o.reset()
+            elif mode == 2:
+                o.fast_reset()
+            else:
+                assert o.frame == frame
+        assert row == len(T)
+        ticks += row
+    assert ticks == 54603

@@ -39,9 +39,10 @@ def main():
             w.writeheader()
             w.writerows(rows)
         for r in rows:
-            if "npp_step_kernel" in r["Name"]:
-                out["step_kernel"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
-                                      "max_ns": float(r["MaxNs"])}
+            for key, pat in (("step_kernel", "npp_step_kernel"), ("render_kernel", "npp_render_kernel")):
+                if pat in r["Name"]:
+                    out[key] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                "max_ns": float(r["MaxNs"])}
     kt = find(os.path.join(src, "trace"), "*kernel_trace.csv")
     if kt and "step_kernel" in out:
         # the bench's timed region = the LAST `steps` dispatches of the step kernel (warm-up launches come first)
@@ -55,10 +56,19 @@ def main():
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
         out["step_kernel"]["timed_region_avg_ns"] = sum(d) / len(d)
         out["step_kernel"]["timed_region_launches"] = len(d)
-        out["step_kernel"]["grid_size"] = last[0].get("Grid_Size")
-        out["step_kernel"]["workgroup_size"] = last[0].get("Workgroup_Size")
-        out["step_kernel"]["vgpr"] = last[0].get("VGPR_Count")
-        out["step_kernel"]["lds_block_size"] = last[0].get("LDS_Block_Size")
+        # launch descriptor as the kernel trace reports it (arch VGPRs and AGPRs are separate columns; LDS is the dynamic +
+        # static allocation of the dispatch; scratch in bytes per lane)
+        for col, name in (("Grid_Size_X", "grid_size_x"), ("Workgroup_Size_X", "workgroup_size_x"), ("VGPR_Count", "arch_vgpr"),
+                          ("Accum_VGPR_Count", "agpr"), ("SGPR_Count", "sgpr"), ("Scratch_Size", "scratch_bytes_per_lane"),
+                          ("LDS_Block_Size", "lds_bytes_per_workgroup")):
+            out["step_kernel"][name] = last[0].get(col)
+        rr = [r for r in csv.DictReader(open(kt)) if "npp_render_kernel" in r["Kernel_Name"]]
+        if rr and "render_kernel" in out:
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rr[-steps:]]
+            out["render_kernel"]["timed_region_avg_ns"] = sum(d) / len(d)
+            for col, name in (("Grid_Size_X", "grid_size_x"), ("VGPR_Count", "arch_vgpr"), ("Accum_VGPR_Count", "agpr"),
+                              ("Scratch_Size", "scratch_bytes_per_lane"), ("LDS_Block_Size", "lds_bytes_per_workgroup")):
+                out["render_kernel"][name] = rr[-1].get(col)
     traffic = {}
     for name in ("fetch", "write"):
         cc = find(os.path.join(src, name), "*counter_collection.csv")
@@ -78,9 +88,28 @@ def main():
         }
         if fs is not None and ws is not None:
             out["traffic"]["hbm_bytes_per_launch"] = fs * 2048 + ws * 1024
+    rtraffic = {}
+    for name in ("fetch", "write"):
+        cc = find(os.path.join(src, name), "*counter_collection.csv")
+        if cc:
+            rtraffic.update(counter_means(cc, "npp_render_kernel"))
+    if rtraffic:
+        # the render kernel reads with dword loads and writes with dword stores: FETCH_SIZE recorded raw and x2 (the x2
+        # correction is calibrated for 16 B / lane streams only); WRITE_SIZE is exact for coalesced stores
+        fs = rtraffic.get("FETCH_SIZE", {}).get("mean_per_dispatch")
+        ws = rtraffic.get("WRITE_SIZE", {}).get("mean_per_dispatch")
+        out["render_traffic"] = {"FETCH_SIZE_mean": fs, "WRITE_SIZE_mean": ws,
+                                 "read_bytes_per_launch_raw": None if fs is None else fs * 1024,
+                                 "read_bytes_per_launch_x2": None if fs is None else fs * 2048,
+                                 "write_bytes_per_launch": None if ws is None else ws * 1024}
+        if fs is not None and ws is not None:
+            out["render_traffic"]["hbm_bytes_per_launch"] = fs * 2048 + ws * 1024
     sq = find(os.path.join(src, "sq"), "*counter_collection.csv")
     if sq:
         out["sq"] = counter_means(sq)
+        rs = counter_means(sq, "npp_render_kernel")
+        if rs:
+            out["sq_render"] = rs
     bl = os.path.join(src, "bench_line.json")
     if os.path.isfile(bl) and os.path.getsize(bl):
         out["bench_line_under_profiler"] = json.loads(open(bl).read())
