@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnpp_amd.so")
+# NPP_AMD_LIB selects another build of the same library (tools/ab_bench.py-style A/B runs of kernel variants)
+LIB_PATH = os.environ.get("NPP_AMD_LIB") or os.path.join(_HERE, "libnpp_amd.so")
 
 NPP_OK = 0
 FLAG_AUTORESET = 1

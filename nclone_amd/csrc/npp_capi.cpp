@@ -202,6 +202,7 @@ int ensure_canvas(npp_handle h) {
     if (h->d_canvas) return NPP_OK;
     const size_t bytes = (size_t)h->levels.size() * 600 * 1056 + 16;   // + 16: rows are read as aligned dword pairs
     HIP_TRY(h, hipMalloc((void **)&h->d_canvas, bytes));
+    HIP_TRY(h, launch_tile_tables(h->stream));   // idempotent: every handle of a device writes the same bytes
     HIP_TRY(h, launch_tile_canvas(h->d_hdr, h->d_blob, h->d_canvas, (int)h->levels.size(), h->stream));
     return NPP_OK;
 }
@@ -421,6 +422,7 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         H.off_ent_perm = append(L.ent_perm.data(), 2 * L.ent_perm.size(), 4);
         H.off_ent_ident = append(L.ent_ident.data(), 2 * L.ent_ident.size(), 4);
         H.off_keep_words = append(L.ent_keep_words.data(), 4 * L.ent_keep_words.size(), 4);
+        H.off_draw_recs = append(L.draw_recs.data(), 4 * L.draw_recs.size(), 16);
         H.n_mov = (uint32_t)L.mov_meta.size();
         H.n_zdoor = (uint32_t)(L.door_tab.size() / 2);
         H.n_created = (uint32_t)L.n_created;

@@ -51,7 +51,7 @@ struct LevelHdr {
     uint32_t off_ent_perm;  // u16[n_ent] CSR walk order after a fast reset
     uint32_t off_ent_ident; // u16[n_ent] identity walk order
     uint32_t off_keep_words;  // u32[n_words] state bits a fast reset keeps
-    uint32_t pad2_;
+    uint32_t off_draw_recs;   // uint4[n_ent + n_mov] drawables in draw order (npp_level.hpp: draw_recs); 16-byte aligned
     double db_count;
     int32_t locked_slots[5];   // CSR slots of the first five locked doors (entity_dic[6] order), -1 = none
     int32_t pad_;
@@ -146,6 +146,7 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
 hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
 hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *d_out, hipStream_t s);
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
+hipError_t launch_tile_tables(hipStream_t s);   // per-device tile gray tables of the player_frame kernel
 hipError_t launch_tile_canvas(const LevelHdr *d_hdr, const unsigned char *d_blob, uint8_t *d_canvas, int n_levels, hipStream_t s);
 
 }  // namespace npp

@@ -341,6 +341,22 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         });
         L.raster_order.clear();
         for (const DrawRef &d : dr) L.raster_order.push_back(d.ref);
+        L.draw_recs.clear();
+        for (uint16_t ref : L.raster_order) {
+            float fx = 0.f, fy = 0.f;
+            uint32_t info;
+            if (ref & 0x8000u) {
+                const RawMover &m = movers[ref & 0x7fffu];
+                info = (m.kind & 15u) | ((m.type & 63u) << 4) | ((m.orientation & 7u) << 10) | 0x8000u | ((uint32_t)(ref & 0x7fffu) << 16);
+            } else {
+                const uint32_t mm = L.ent_meta[ref];
+                fx = (float)L.ent_x[ref]; fy = (float)L.ent_y[ref];
+                info = (mm & 15u) | (((mm >> 24) & 63u) << 4) | (((mm >> 8) & 7u) << 10) | ((uint32_t)ref << 16);
+            }
+            uint32_t bx, by;
+            std::memcpy(&bx, &fx, 4); std::memcpy(&by, &fy, 4);
+            L.draw_recs.push_back(bx); L.draw_recs.push_back(by); L.draw_recs.push_back(info); L.draw_recs.push_back(0u);
+        }
         for (auto &d : raw_doors) {
             for (int k = 0; k < 4; k++) L.door_segs.push_back(d[k]);
             L.door_segs.push_back((double)slot_of[(int)d[4]]);

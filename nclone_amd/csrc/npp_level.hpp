@@ -40,6 +40,9 @@ struct CompiledLevel {
     std::vector<uint32_t> ent_init_words;  // 2 bits per entity, 16 per word
     std::vector<uint8_t> tiles;        // [N_CELLS] tile id per cell (border = 1), for the rasteriser
     std::vector<uint16_t> raster_order;  // CSR slots in draw order (entity_renderer.py:100-150: by type, then map order)
+    // the same walk as compact records for the rasteriser, 4 u32 per drawable: x, y (float bits; unused for movers),
+    // kind | raw type << 4 | orientation << 10 | mover << 15 | (CSR slot or mover index) << 16, 0
+    std::vector<uint32_t> draw_recs;
     std::vector<double> door_segs;     // closed-door strokes: x1, y1, x2, y2, slot of the owning entity (5 per door)
     double spawn_x = 0, spawn_y = 0;
     int obs_switch = -1, obs_door = -1;  // CSR slots of the exit switch / door reported in observations

@@ -13,8 +13,6 @@
 // here is 4x4 supersampling, so pixels away from primitive edges are exact and edge pixels differ by a few levels.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "npp_internal.hpp"
 #include "npp_level.hpp"
 
@@ -83,13 +81,23 @@ __device__ inline bool tile_inside(int t, float u, float v) {   // (u, v) in [0,
 __device__ inline int draw_cover(const Draw &d, int x, int y) {
     int cnt = 0;
     if (d.shape == 0) {
-        float ddx = (x + 0.5f) - d.x, ddy = (y + 0.5f) - d.y, lim = d.r + 1.f;
-        if (ddx * ddx + ddy * ddy > lim * lim) return 0;
+        // the pixel square [x, x + 1] x [y, y + 1] against the disc: entirely outside (its nearest point is) or entirely
+        // inside (its farthest corner is) without sampling -- only the pixels on the rim run the 16 samples
+        const float ax = x - d.x, ay = y - d.y, r2 = d.r * d.r;
+        const float nx = fmaxf(fmaxf(ax, -(ax + 1.f)), 0.f), ny = fmaxf(fmaxf(ay, -(ay + 1.f)), 0.f);
+        if (nx * nx + ny * ny > r2) return 0;
+        const float fx = fmaxf(fabsf(ax), fabsf(ax + 1.f)), fy = fmaxf(fabsf(ay), fabsf(ay + 1.f));
+        if (fx * fx + fy * fy <= r2) return 16;
+        float qx2[4], qy2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float qx = x + (k + 0.5f) * 0.25f - d.x, qy = y + (k + 0.5f) * 0.25f - d.y;
+            qx2[k] = qx * qx; qy2[k] = qy * qy;
+        }
+#pragma unroll
         for (int sy = 0; sy < 4; sy++)
-            for (int sx = 0; sx < 4; sx++) {
-                float qx = x + (sx + 0.5f) * 0.25f - d.x, qy = y + (sy + 0.5f) * 0.25f - d.y;
-                cnt += (qx * qx + qy * qy <= d.r * d.r) ? 1 : 0;
-            }
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) cnt += (qx2[sx] + qy2[sy] <= r2) ? 1 : 0;
     } else if (d.shape == 1) {
         float vx = d.x2 - d.x, vy = d.y2 - d.y, len = sqrtf(vx * vx + vy * vy);
         if (len <= 0.f) return 0;
@@ -102,11 +110,13 @@ __device__ inline int draw_cover(const Draw &d, int x, int y) {
             }
     } else {
         if (fabsf((x + 0.5f) - d.x) > d.r + 1.f || fabsf((y + 0.5f) - d.y) > d.r + 1.f) return 0;
-        for (int sy = 0; sy < 4; sy++)
-            for (int sx = 0; sx < 4; sx++) {
-                float qx = x + (sx + 0.5f) * 0.25f - d.x, qy = y + (sy + 0.5f) * 0.25f - d.y;
-                cnt += (fabsf(qx) <= d.r && fabsf(qy) <= d.r) ? 1 : 0;
-            }
+        int nx = 0, ny = 0;   // the square is a product of two intervals: samples inside = columns inside x rows inside
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            nx += (fabsf(x + (k + 0.5f) * 0.25f - d.x) <= d.r) ? 1 : 0;
+            ny += (fabsf(y + (k + 0.5f) * 0.25f - d.y) <= d.r) ? 1 : 0;
+        }
+        cnt = nx * ny;
     }
     return cnt;
 }
@@ -330,158 +340,302 @@ __device__ inline Window frame_window(double px, double py, int centered) {
     return {row0, col0, h, w, (FH - h) / 2, (FW - w) / 2};
 }
 
-// ---- player_frame ------------------------------------------------------------------------------------------------------
-// Per env: the window's draw list (LDS), a per-output-row bit mask of the drawables whose rows it can touch (LDS), and the
-// 17 possible gray values of a pixel without entity coverage (tile coverage count -> gray; LDS).  A lane produces 4
-// horizontally adjacent pixels per pass and stores them as one dword (a wavefront writes 256 contiguous bytes).  The tile
-// layer is two aligned dword loads of the level's coverage canvas per span (the 64 envs of a level share those rows in L2).
-// Spans that no drawable touches -- almost all -- cost two loads, four table look-ups and a store.
-constexpr int PF_MASK_WORDS = (MAX_DRAW + 63) / 64;   // 3
-struct FrameLds {
-    Draw draw[MAX_DRAW];
-    unsigned long long rowmask[FH][PF_MASK_WORDS];
-    unsigned char lut[32];
-};
+// Gray value of a canvas pixel that no entity touches, for every tile id and every pixel of the 24 x 24 cell:
+// g_tile_gray[t][v][u] = composite(0, 0, coverage count of tile t at (u, v)).  19 584 bytes, the same for every level; built
+// once per device (launch_tile_tables) and staged into LDS by the player_frame kernel, which therefore never reads the
+// per-level coverage canvas.  g_gray_cnt inverts it (gray -> coverage count) for the few pixels an entity touches.
+constexpr int TILE_TAB = 34 * 576;
+__device__ __attribute__((aligned(16))) unsigned char g_tile_gray[TILE_TAB];
+__device__ unsigned char g_gray_cnt[256];
 
-// rows of the OUTPUT frame touched by drawable k (conservative: extent + 1 px of anti-aliasing)
-__device__ inline void frame_rowmasks(FrameLds &L, int nd, const Window &wd, int t, int nthreads) {
-    for (int r = t; r < FH; r += nthreads) {
-        unsigned long long m[PF_MASK_WORDS] = {};
-        const int fr = r - wd.top;
-        if (fr >= 0 && fr < wd.h) {
-            const float y = (float)(wd.row0 + fr);
-            for (int k = 0; k < nd; k++) {
-                float cx, cy, ex, ey;
-                draw_extent(L.draw[k], cx, cy, ex, ey);
-                if (!(cy + ey < y || cy - ey > y + 1.f)) m[k >> 6] |= 1ull << (k & 63);
-            }
-        }
-        for (int q = 0; q < PF_MASK_WORDS; q++) L.rowmask[r][q] = m[q];
-    }
-    for (int c = t; c < 17; c += nthreads) L.lut[c] = (unsigned char)composite(0.f, 0.f, c);
+__global__ __launch_bounds__(256) void npp_tile_tables_kernel() {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 17) g_gray_cnt[composite(0.f, 0.f, i)] = (unsigned char)i;   // the 17 grays are distinct (202 down to 121)
+    if (i >= TILE_TAB) return;
+    const int t = i / 576, v = (i % 576) / 24, u = i % 24;
+    int cnt = 0;
+    if (t == 1) cnt = 16;
+    else if (t)
+        for (int sy = 0; sy < 4; sy++)
+            for (int sx = 0; sx < 4; sx++) cnt += tile_inside(t, u + (sx + 0.5f) * 0.25f, v + (sy + 0.5f) * 0.25f) ? 1 : 0;
+    g_tile_gray[i] = (unsigned char)composite(0.f, 0.f, cnt);
 }
 
-// the four pixels (r, c0 .. c0 + 3) of the output frame, packed little-endian
-__device__ inline uint32_t frame_span(const FrameLds &L, const Window &wd, const uint8_t *canvas, int r, int c0) {
+// ---- player_frame ------------------------------------------------------------------------------------------------------
+// One workgroup (4 wavefronts) per env.  What the profiles say (profiles/r02_render_*; tools/render_stamps.py): the kernel
+// is bound by VALU issue -- 24 M wavefront-instructions per launch, half of the lanes idle in them -- because every frame
+// holds the ninja (and often an exit door or mines) in its middle rows, and a wavefront whose 64 spans touch such a row
+// used to run the coverage sampler for the few lanes that needed it.  Hence two passes:
+//   pass 1  every lane classifies its 4-pixel spans.  A span over empty / solid tiles (the level's 1100-byte tile table is
+//           staged in LDS) with no drawable's pixel box on it -- almost all spans -- is finished with a handful of integer
+//           instructions and stored as one dword (a wavefront writes 256 contiguous bytes).  Any other span goes to a queue.
+//   pass 2  the queued spans are shaded one PIXEL per lane (4 consecutive lanes per span, recombined with DPP-free shuffles):
+//           the sampler runs on full wavefronts of pixels that need it.
+// Wavefront 0 alone builds the window's draw list from the level's compact draw-order records (one 16-byte load + a window
+// test per candidate; ballot / prefix compaction, no workgroup barrier inside) and ORs every kept drawable into a
+// per-output-row bit mask; the other wavefronts stage the tile table and wait at ONE barrier.
+constexpr int PF_MASK_WORDS = (MAX_DRAW + 63) / 64;   // 3
+constexpr int PF_SPANS = (FW / 4) * FH;               // 1764
+struct FrameLds {
+    Draw draw[MAX_DRAW];
+    short bx0[MAX_DRAW], bx1[MAX_DRAW];              // canvas pixel columns a drawable can touch (inclusive)
+    unsigned long long rowmask[FH][PF_MASK_WORDS];
+    unsigned short queue[PF_SPANS];
+    int nq;
+    int nd;
+    __attribute__((aligned(4))) unsigned char tiles[1100];   // the level's tile ids, cell (cx, cy) at cx * 25 + cy
+    __attribute__((aligned(16))) unsigned char gray[TILE_TAB];   // g_tile_gray
+};
+
+// the drawable of a draw-order record (entity_renderer.py:100-150), given the entity's position and 2-bit state
+__device__ inline bool rec_drawable(uint32_t info, float x, float y, uint32_t st, Draw &out) {
+    const uint32_t kind = info & 15u, type = (info >> 4) & 63u;
+    if (info & 0x8000u) {   // movers (kind = MoverKind)
+        if (kind == MK_DRONE) out = {x, y, 7.5f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};
+        else if (kind == MK_MINI) out = {x, y, 4.f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};
+        else if (kind == MK_BOUNCE) out = {x, y, 9.f, 0.f, 0.f, (float)luma(0xE3, 0xE3, 0xE5), 2};
+        else if (kind == MK_THWUMP) out = {x, y, 9.f, 0.f, 0.f, (float)luma(0x83, 0x83, 0x84), 2};
+        else if (kind == MK_BALL) out = {x, y, 5.f, 0.f, 0.f, (float)luma(0x15, 0xA7, 0xBD), 0};
+        else out = {x, y, 8.f, 0.f, 0.f, (float)luma(0x6E, 0xC9, 0xE0), 0};   // shove thwump: RADIUS wins over SEMI_SIDE
+        return true;
+    }
+    if (kind == EK_MINE) {             // always active; radius follows the state
+        out = {x, y, st == 0 ? 4.0f : (st == 1 ? 3.5f : 4.5f), 0.f, 0.f,
+               type == 1 ? (float)luma(0x9E, 0x21, 0x26) : (float)luma(0xCE, 0x41, 0x46), 0};
+        return true;
+    }
+    if (kind == EK_EXIT) {             // always active; dark blue (0, 0, 0.5) once the switch was hit
+        out = {x, y, 12.f, 0.f, 0.f, st ? (float)luma(0, 0, 128) : (float)luma(0x83, 0x83, 0x84), 0};
+        return true;
+    }
+    if (kind == EK_DOOR_REG) return false;   // entity_renderer.py:104-105
+    if ((st & 1u) == 0) return false;        // collected gold / switches are inactive and not drawn
+    if (kind == EK_GOLD) out = {x, y, 6.f, 0.f, 0.f, (float)luma(0xDB, 0xE1, 0x49), 0};
+    else if (kind == EK_SWITCH) out = {x, y, 6.f, 0.f, 0.f, (float)luma(0x6D, 0x97, 0xC3), 0};
+    else if (kind == EK_BOOST) out = {x, y, 6.f, 0.f, 0.f, (float)luma(0x66, 0x66, 0x66), 0};
+    else if (kind == EK_LAUNCH || kind == EK_ONEWAY) {
+        // _draw_oriented_entity: angle = atan2(nx, ny) + pi/2; end points (x +- sin(angle) R, y +- cos(angle) R)
+        const uint32_t o = (info >> 10) & 7u;
+        const float dg = 0.70710678f;
+        const int sx = (o == 0 || o == 1 || o == 7) ? 1 : ((o >= 3 && o <= 5) ? -1 : 0);
+        const int sy = (o >= 1 && o <= 3) ? 1 : ((o >= 5) ? -1 : 0);
+        const float nx = (o & 1) ? sx * dg : (float)sx, ny = (o & 1) ? sy * dg : (float)sy;
+        const float R = kind == EK_LAUNCH ? 6.f : 12.f;
+        out = {x + ny * R, y - nx * R, 1.5f, x - ny * R, y + nx * R,
+               kind == EK_LAUNCH ? (float)luma(0x86, 0x87, 0x93) : (float)luma(0x66, 0x66, 0x66), 1};   // PLATFORMWIDTH 3
+    } else out = {x, y, 5.f, 0.f, 0.f, 0.f, 0};   // locked / trap door switch: black
+    return true;
+}
+
+// Executed by ONE wavefront (lane = 0..63): fills L.draw / L.bx0 / L.bx1 / L.nd / L.rowmask for the window of `wd`.
+__device__ inline void frame_build(FrameLds &L, const KernelArgs &a, const LevelHdr &H, int env, double px, double py, const Window &wd,
+                                   int lane) {
+    for (int i = lane; i < FH * PF_MASK_WORDS; i += 64) (&L.rowmask[0][0])[i] = 0ull;
+    if (lane == 0) L.nq = 0;
+    const float wx0 = wd.col0 - 16.f, wy0 = wd.row0 - 16.f, wx1 = wd.col0 + wd.w + 16.f, wy1 = wd.row0 + wd.h + 16.f;
+    int nd = 0;   // wavefront-uniform
+    auto append = [&](bool keep, const Draw &d) {
+        const unsigned long long bal = __ballot(keep);
+        if (bal == 0) return;
+        const int pos = nd + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && pos < MAX_DRAW - 1) {
+            L.draw[pos] = d;
+            // output rows / canvas columns this drawable can touch (extent + 1 px of anti-aliasing)
+            float cx, cy, ex, ey;
+            draw_extent(d, cx, cy, ex, ey);
+            L.bx0[pos] = (short)((int)floorf(cx - ex) - 1);
+            L.bx1[pos] = (short)((int)ceilf(cx + ex));
+            int y0 = (int)floorf(cy - ey) - 1, y1 = (int)ceilf(cy + ey);
+            int r0 = y0 - wd.row0 + wd.top, r1 = y1 - wd.row0 + wd.top;
+            r0 = r0 < wd.top ? wd.top : r0;
+            r1 = r1 > wd.top + wd.h - 1 ? wd.top + wd.h - 1 : r1;
+            const unsigned long long bit = 1ull << (pos & 63);
+            for (int r = r0; r <= r1; r++) atomicOr(&L.rowmask[r][pos >> 6], bit);
+        }
+        nd += __popcll(bal);
+    };
+    if (H.n_door) {   // closed door strokes first (entity_renderer.py:63-97)
+        DrawCtx c{&a, &H, env, wx0, wy0, wx1, wy1};
+        for (uint32_t d0 = 0; d0 < H.n_door; d0 += 64) {
+            Draw d = {};
+            const uint32_t k = d0 + lane;
+            append(k < H.n_door && door_drawable(c, k, d), d);
+        }
+    }
+    const uint4 *recs = reinterpret_cast<const uint4 *>(a.blob + H.off_draw_recs);
+    const uint32_t n_draw = H.n_ent + H.n_mov;
+    const double *zhead = a.zoo ? a.zoo + (size_t)env * a.zoo_words : nullptr;
+    const uint32_t ovr = zhead ? reinterpret_cast<const uint32_t *>(zhead + 3)[0] : 0u;   // npp_set_entity_pos
+    for (uint32_t k0 = 0; k0 < n_draw; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        bool keep = false;
+        Draw d = {};
+        if (k < n_draw) {
+            const uint4 rc = recs[k];
+            float x = __uint_as_float(rc.x), y = __uint_as_float(rc.y);
+            const uint32_t info = rc.z;
+            const int slot = (int)(info >> 16);
+            bool live = true;
+            if (info & 0x8000u) {   // a mover: position from the env's zoo block
+                live = zhead != nullptr && H.has_zoo;
+                if (live) {
+                    const double *zb = zhead + ZOO_HEAD + (a.zoo_doors + 1) / 2 + ZOO_MOV_WORDS * slot;
+                    x = (float)zb[0]; y = (float)zb[1];
+                }
+            } else if (ovr) {
+                if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)zhead[4]; y = (float)zhead[5]; }
+                if (slot == H.obs_door && (ovr & ZOO_OVR_DOOR)) { x = (float)zhead[6]; y = (float)zhead[7]; }
+            }
+            if (live && !(x < wx0 || x > wx1 || y < wy0 || y > wy1)) {
+                const uint32_t st = (info & 0x8000u) ? 1u : ent_state_of(a, env, slot);
+                keep = rec_drawable(info, x, y, st, d);
+            }
+        }
+        append(keep, d);
+    }
+    nd = nd < MAX_DRAW - 1 ? nd : MAX_DRAW - 1;
+    {   // the ninja, drawn last
+        Draw d = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};
+        append(lane == 0, d);
+    }
+    if (lane == 0) L.nd = nd < MAX_DRAW ? nd : MAX_DRAW;
+}
+
+// gray of canvas pixel (x, y) without entities: the cell's tile id (glitched ids 34+ are solid) and the pixel inside the cell
+__device__ inline uint32_t tile_gray(const FrameLds &L, uint32_t x, uint32_t y) {
+    const uint32_t cx = x / 24u, cy = y / 24u;
+    uint32_t t = L.tiles[cx * 25u + cy];
+    t = t > 33u ? 1u : t;
+    return L.gray[t * 576u + (y - cy * 24u) * 24u + (x - cx * 24u)];
+}
+
+// pass 1: the span's four pixels packed little-endian when no entity can touch it and it has no padding pixel; otherwise
+// `slow` is set and the value is meaningless
+__device__ inline uint32_t span_plain(const FrameLds &L, const Window &wd, int r, int c0, bool &slow) {
+    slow = false;
     const int fr = r - wd.top;
-    if (fr < 0 || fr >= wd.h) return 0;   // cv2.copyMakeBorder(..., value=0)
-    const int y = wd.row0 + fr;
-    const int xs = wd.col0 + c0 - wd.left;   // canvas x of the span's first pixel (pixels outside [col0, col0 + w) are padding)
-    // tile coverage of the span: two aligned dwords of the level's canvas row
-    const int xb = xs < 0 ? 0 : (xs > 1052 ? 1052 : xs);
-    const uint32_t *crow = reinterpret_cast<const uint32_t *>(canvas + (size_t)y * 1056) + (xb >> 2);
-    const unsigned long long tl = (unsigned long long)crow[0] | ((unsigned long long)crow[1] << 32);
-    const int obase = xs - (xb & ~3);
-    float eg[4] = {0.f, 0.f, 0.f, 0.f}, ea[4] = {0.f, 0.f, 0.f, 0.f};
-    bool touched = false;
+    if (fr < 0 || fr >= wd.h) return 0;   // rows outside the window are padding: cv2.copyMakeBorder(..., value=0)
+    const int y = wd.row0 + fr, xs = wd.col0 + c0 - wd.left;
+    slow = true;
+    if (c0 - wd.left < 0 || c0 + 3 - wd.left >= wd.w) return 0;   // padding pixels in the span
     for (int q = 0; q < PF_MASK_WORDS; q++) {
         unsigned long long m = L.rowmask[r][q];
         while (m) {
             const int k = q * 64 + __builtin_ctzll(m);
             m &= m - 1;
+            if (L.bx1[k] >= xs && L.bx0[k] <= xs + 3) return 0;
+        }
+    }
+    slow = false;
+    const uint32_t cy = (uint32_t)y / 24u, v = (uint32_t)y - cy * 24u;
+    const uint32_t cx0 = (uint32_t)xs / 24u, cx1 = (uint32_t)(xs + 3) / 24u;
+    uint32_t t0 = L.tiles[cx0 * 25u + cy], t1 = L.tiles[cx1 * 25u + cy];
+    t0 = t0 > 33u ? 1u : t0; t1 = t1 > 33u ? 1u : t1;
+    const uint32_t b0 = t0 * 576u + v * 24u, b1 = t1 * 576u + v * 24u;
+    const uint32_t u0 = (uint32_t)xs - cx0 * 24u;   // column of the span's first pixel inside its cell (0..23)
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t u = u0 + j;   // a column >= 24 lies in the next cell
+        out |= (uint32_t)L.gray[u < 24u ? b0 + u : b1 + u - 24u] << (8 * j);
+    }
+    return out;
+}
+
+// pass 2: one pixel (r, c) of the output frame in full generality
+__device__ inline uint32_t pixel_full(const FrameLds &L, const Window &wd, const unsigned char *gray_cnt, int r, int c) {
+    const int fr = r - wd.top, fc = c - wd.left;
+    if (fr < 0 || fr >= wd.h || fc < 0 || fc >= wd.w) return 0;
+    const int y = wd.row0 + fr, x = wd.col0 + fc;
+    const uint32_t g = tile_gray(L, (uint32_t)x, (uint32_t)y);
+    float eg = 0.f, ea = 0.f;
+    for (int q = 0; q < PF_MASK_WORDS; q++) {
+        unsigned long long m = L.rowmask[r][q];
+        while (m) {
+            const int k = q * 64 + __builtin_ctzll(m);
+            m &= m - 1;
+            if (L.bx1[k] < x || L.bx0[k] > x) continue;
             const Draw &d = L.draw[k];
-            float cx, cy, ex, ey;
-            draw_extent(d, cx, cy, ex, ey);
-            if (cx + ex < xs || cx - ex > xs + 4) continue;
-            touched = true;
-#pragma nounroll
-            for (int j = 0; j < 4; j++) {
-                const int cnt = draw_cover(d, xs + j, y);
-                if (cnt) {
-                    float cov = cnt * (1.f / 16.f);
-                    eg[j] = eg[j] * (1.f - cov) + d.gray * cov;
-                    ea[j] = ea[j] * (1.f - cov) + cov;
-                }
+            const int cv = draw_cover(d, x, y);
+            if (cv) {
+                float cov = cv * (1.f / 16.f);
+                eg = eg * (1.f - cov) + d.gray * cov;
+                ea = ea * (1.f - cov) + cov;
             }
         }
     }
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int fc = c0 + j - wd.left;
-        if (fc >= 0 && fc < wd.w) {
-            const int cnt = (int)((tl >> (8 * (obase + j))) & 0xffull);
-            const int v = touched ? composite(eg[j], ea[j], cnt) : (int)L.lut[cnt];
-            packed |= (uint32_t)v << (8 * j);
-        }
-    }
-    return packed;
+    if (ea == 0.f) return g;
+    return (uint32_t)composite(eg, ea, (int)gray_cnt[g]);
 }
 
-// One WORKGROUP per env (default).
-__global__ __launch_bounds__(256) void npp_render_kernel(KernelArgs a, uint8_t *out, int centered) {
+#ifndef NPP_RENDER_OCC
+#define NPP_RENDER_OCC 5
+#endif
+__global__ __launch_bounds__(256, NPP_RENDER_OCC) void npp_render_kernel(KernelArgs a, uint8_t *out, int centered) {
     __shared__ FrameLds L;
-    __shared__ int s_n;
-    __shared__ int s_wc[4];
     const int env = blockIdx.x;
     if (env >= a.n) return;
-    const int lvl = a.env_level[env];
+#ifdef NPP_RENDER_STAMPS
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const int lvl = __builtin_amdgcn_readfirstlane(a.env_level[env]);
     const LevelHdr &H = a.hdr[lvl];
     const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
     const Window wd = frame_window(px, py, centered);
     uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)env * FW * FH);
     constexpr int DW_PER_ROW = FW / 4;   // 21
+#ifdef NPP_RENDER_STAMPS
+    const unsigned long long t1 = wd.h ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memtime();
+#endif
     if (wd.h == 0 || wd.w == 0) {        // the window lies outside the canvas (axis swap with player_x > 642): all padding
         for (int q = threadIdx.x; q < DW_PER_ROW * FH; q += blockDim.x) dst[q] = 0;
         return;
     }
-    build_draw_list(a, H, env, px, py, wd.col0 - 16.f, wd.row0 - 16.f, wd.col0 + wd.w + 16.f, wd.row0 + wd.h + 16.f, L.draw, MAX_DRAW,
-                    &s_n, s_wc);
-    const int nd = s_n;
-    frame_rowmasks(L, nd, wd, threadIdx.x, blockDim.x);
+    {   // stage the level's tile ids (1100 bytes; 64 envs per level keep the source in L2) and the tile gray table (19 584
+        // bytes, the same for every workgroup of the launch)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.blob + H.off_tiles);
+        uint32_t *dstw = reinterpret_cast<uint32_t *>(L.tiles);
+        for (int i = threadIdx.x; i < 275; i += blockDim.x) dstw[i] = src[i];
+        const uint4 *gs = reinterpret_cast<const uint4 *>(g_tile_gray);
+        uint4 *gd = reinterpret_cast<uint4 *>(L.gray);
+        for (int i = threadIdx.x; i < TILE_TAB / 16; i += blockDim.x) gd[i] = gs[i];
+    }
+    if (threadIdx.x < 64) frame_build(L, a, H, env, px, py, wd, threadIdx.x);
+#ifdef NPP_RENDER_STAMPS
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
-    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
-    for (int q = threadIdx.x; q < DW_PER_ROW * FH; q += blockDim.x) {
+#ifdef NPP_RENDER_STAMPS
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int q = threadIdx.x; q < PF_SPANS; q += blockDim.x) {   // pass 1
         const int r = q / DW_PER_ROW, c0 = (q - r * DW_PER_ROW) * 4;
-        dst[q] = frame_span(L, wd, canvas, r, c0);
+        bool slow;
+        const uint32_t v = span_plain(L, wd, r, c0, slow);
+        if (slow) L.queue[atomicAdd(&L.nq, 1)] = (unsigned short)q;
+        else dst[q] = v;
     }
-}
-
-// One WAVEFRONT per env, four envs per workgroup, no workgroup barrier (a wavefront's LDS traffic is ordered, so the list it
-// compacts with ballot / prefix is its own).  A/B variant: NPP_RENDER_WAVE=1.
-__global__ __launch_bounds__(256) void npp_render_wave_kernel(KernelArgs a, uint8_t *out, int centered) {
-    __shared__ FrameLds Ls[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int env = blockIdx.x * 4 + wave;
-    if (env >= a.n) return;   // the whole wavefront leaves; nobody waits for it
-    FrameLds &L = Ls[wave];
-    const int lvl = a.env_level[env];
-    const LevelHdr &H = a.hdr[lvl];
-    const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
-    const Window wd = frame_window(px, py, centered);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)env * FW * FH);
-    constexpr int DW_PER_ROW = FW / 4;   // 21
-    if (wd.h == 0 || wd.w == 0) {
-        for (int q = lane; q < DW_PER_ROW * FH; q += 64) dst[q] = 0;
-        return;
+    __syncthreads();
+#ifdef NPP_RENDER_STAMPS
+    const unsigned long long t3b = __builtin_amdgcn_s_memtime();
+#endif
+    const int npix = L.nq * 4;
+    for (int i = threadIdx.x; i < npix; i += blockDim.x) {   // pass 2: lanes 4 m .. 4 m + 3 shade the pixels of one span
+        const int q = L.queue[i >> 2], j = i & 3;
+        const int r = q / DW_PER_ROW, c = (q - r * DW_PER_ROW) * 4 + j;
+        uint32_t v = pixel_full(L, wd, g_gray_cnt, r, c) << (8 * j);
+        v |= __shfl_xor(v, 1, 64);
+        v |= __shfl_xor(v, 2, 64);
+        if (j == 0) dst[q] = v;
     }
-    int nd = 0;   // wavefront-uniform
-    {
-        DrawCtx c{&a, &H, env, wd.col0 - 16.f, wd.row0 - 16.f, wd.col0 + wd.w + 16.f, wd.row0 + wd.h + 16.f};
-        const uint32_t n_draw = H.n_ent + H.n_mov;
-        for (uint32_t k0 = 0; k0 < H.n_door + n_draw; k0 += 64) {   // doors first, then the entities in draw order
-            Draw d = {};
-            const uint32_t k = k0 + lane;
-            bool keep = false;
-            if (k < H.n_door) keep = door_drawable(c, k, d);
-            else if (k < H.n_door + n_draw) keep = entity_drawable(c, k - H.n_door, d);
-            const unsigned long long bal = __ballot(keep);
-            const int pos = nd + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep && pos < MAX_DRAW - 1) L.draw[pos] = d;
-            nd += __popcll(bal);
-        }
-        nd = nd < MAX_DRAW - 1 ? nd : MAX_DRAW - 1;
-        if (lane == 0) L.draw[nd] = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};   // the ninja, drawn last
-        nd++;
-        __builtin_amdgcn_wave_barrier();
+#ifdef NPP_RENDER_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) {   // diagnostic build only: phase durations (shader clocks) over the frame's first bytes
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        dst[0] = (uint32_t)(t1 - t0); dst[1] = (uint32_t)(t2 - t1); dst[2] = (uint32_t)(t3 - t2); dst[3] = (uint32_t)(t4 - t3);
+        dst[4] = (uint32_t)L.nd; dst[5] = H.n_ent + H.n_mov; dst[6] = (uint32_t)L.nq; dst[7] = (uint32_t)(t3b - t3);
     }
-    frame_rowmasks(L, nd, wd, lane, 64);
-    __builtin_amdgcn_wave_barrier();
-    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
-    for (int q = lane; q < DW_PER_ROW * FH; q += 64) {
-        const int r = q / DW_PER_ROW, c0 = (q - r * DW_PER_ROW) * 4;
-        dst[q] = frame_span(L, wd, canvas, r, c0);
-    }
+#endif
 }
 
 // global_view (observation_processor.py:304-328): cv2.resize(frame, (RENDERED_VIEW_WIDTH = 100, RENDERED_VIEW_HEIGHT = 176),
@@ -643,14 +797,17 @@ hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s
 }
 
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s) {
-    static const bool wave = std::getenv("NPP_RENDER_WAVE") != nullptr;   // A/B aid: the one-wavefront-per-env variant
-    if (wave) hipLaunchKernelGGL(npp_render_wave_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, a, d_out, centered);
-    else hipLaunchKernelGGL(npp_render_kernel, dim3(a.n), dim3(256), 0, s, a, d_out, centered);
+    hipLaunchKernelGGL(npp_render_kernel, dim3(a.n), dim3(256), 0, s, a, d_out, centered);
     return hipGetLastError();
 }
 
 hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s) {
     hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n), dim3(256), 0, s, a, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_tables(hipStream_t s) {
+    hipLaunchKernelGGL(npp_tile_tables_kernel, dim3((TILE_TAB + 255) / 256), dim3(256), 0, s);
     return hipGetLastError();
 }
 
