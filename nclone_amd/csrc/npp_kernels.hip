@@ -1665,11 +1665,15 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 
 // LDS_LEVEL is chosen by the host: true when every workgroup's envs play one level that fits the LDS budget
 // (the host knows the env -> level assignment), false otherwise (tables are read through L1/L2).
-// Register budget: the second launch-bound argument is the minimum number of wavefronts per SIMD.  Two per SIMD (<= 256
-// unified VGPR + AGPR) keep all 2048 wavefronts of an 8192-env launch resident at once (1024 SIMDs); the zoo kernels carry
-// far more state and stay at one.
+// Register budget: the second launch-bound argument is the minimum number of wavefronts per SIMD.  Measured on MI355X
+// (profiles/r02_occupancy_ab.txt, tools/occupancy_ab.py): capping the kernel at 256 unified registers (2 wavefronts per SIMD,
+// all 2048 wavefronts of an 8192-env launch resident at once) changes NOTHING at 8192 envs (160.7 vs 160.5 us: the launch
+// lasts as long as its slowest env's serial chain, not as long as its wavefronts queue) and LOSES at the batch sizes where
+// throughput matters (32 768 envs, G = 8: 699 vs 404 us; 65 536 envs, G = 4: 810 vs 555 us) because the G <= 8
+// instantiations then spill ~360 VGPRs to scratch.  So the allocator keeps its free hand (1 wavefront per SIMD, AGPRs as
+// spill space); -DNPP_MIN_WAVES=2 rebuilds the capped variant for A/B runs.
 #ifndef NPP_MIN_WAVES
-#define NPP_MIN_WAVES 2
+#define NPP_MIN_WAVES 1
 #endif
 template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
 __global__ __launch_bounds__(256, (ZOO ? 1 : NPP_MIN_WAVES)) void npp_step_kernel(KernelArgs a) {
