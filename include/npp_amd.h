@@ -163,6 +163,19 @@ int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y);
  * switch position (its segment has no `p1`), reproduced.  No runnable reference for this one: parity by source reading. */
 int npp_switch_states(npp_handle h, float *d_out);
 
+/* reachability_features (f32[n_envs][38]) and mine_sdf_features (f32[n_envs][3]) of the current state of every env: what
+ * ReachabilityMixin._get_reachability_features (gym_environment/mixins/reachability_mixin.py:72-222) and
+ * MineSignedDistanceField.get_features_at_position (graph/reachability/mine_proximity_cache.py:476) return, including the
+ * reference's cache rule -- the 38 floats are recomputed only when (ninja cell, exit_switch_activated) differs from the key of
+ * the env's previous call, so call it once per observation (after npp_step / npp_reset), as the reference does.  The
+ * per-level tables (sub-node graph, entity mask, flood fill, geometric Dijkstra from both goals, mine SDF) are built on the
+ * host at the first call.  Either output may be NULL.  d_status (i32[n_envs], may be NULL): bit 0 set where the reference
+ * would have left its level cache for the physics A* search (no node with a cached distance under the ninja), which is not
+ * restated -- those rows carry the "unreachable" values.  NPP_ERR_UNSUPPORTED: a loaded level needs that search for every
+ * query (several exit switches, or the exit door within 24 px of its switch), or an entity was moved with
+ * npp_set_entity_pos.  Not meaningful between the steps of npp_step_many (the cache rule needs every observation). */
+int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status);
+
 /* The whole gray frame of envs [env0, env0 + count): what NPlayHeadless.render() returns in grayscale mode
  * (nplay_headless.py:144-156, nsim_renderer.py:71-134).  d_out: u8[count][600][1056]. */
 int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out);
@@ -193,6 +206,22 @@ int npp_dump_level_segments(npp_handle h, int level, int16_t *out, int max_rows,
 int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int max_rows, int *n_out,
                                uint32_t *unsupported_mask);
 int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out);
+
+/* Host-only: the per-level reachability tables of one level, stage by stage (CPU tests compare them with the reference's,
+ * tests/golden/reach.npz).  Node id = i * 46 + j for the sub-node at tile-data pixel (6 + 12 i, 6 + 12 j), 84 x 46 = 3864 ids.
+ * info i32[16]: supported, len(adjacency), goal node of exit_switch_0 / exit_door_0 in the level cache, the two goal nodes
+ * get_distance resolves, switch x, y, door x, y (int), goal id inferred for the door position (0 = "switch"), mines, has
+ * SDF, surface area (nodes).  base_in / base_adj / phys: tile-only graph (node present, edge bits N E S W NE SE SW NW,
+ * grounded | walled << 1).  in / adj: final adjacency.  dist f64[2][3864], hop i16[2][3864], mh f64[2][3864][2]: level
+ * cache per goal.  sdf f32[50][88], grad f32[50][88][2].  scalars f64[8]: area scale, feature 0, feature 3, features 25-28.
+ * Any pointer may be NULL. */
+int npp_reach_compile(const double *map, int64_t n, int32_t *info, uint8_t *base_in, uint8_t *base_adj, uint8_t *phys, uint8_t *in,
+                      uint8_t *adj, double *dist, int16_t *hop, double *mh, float *sdf, float *grad, double *scalars);
+/* Host-only: the feature function the device kernel runs (npp_reach_features.hpp compiles for both), on `count` positions
+ * (f64[count][2]) of one level; mines i32[count][2] = (total, deadly) toggle mines (NULL: all safe).  out f32[count][38],
+ * sdf_out f32[count][3] (may be NULL), status i32[count] (may be NULL; bit 0 as in npp_reachability, bit 1 = level unsupported). */
+int npp_reach_features_host(const double *map, int64_t n, const double *pos, const int32_t *mines, int count, float *out, float *sdf_out,
+                            int32_t *status);
 
 /* Host-only: the zoo tables the level compiler derives from map_data.  edges_out: int32[2][89*51] grid-edge counters at
  * load (horizontal then vertical, key = x * 51 + y; tile edges of tile_segment_factory.py:283-302 plus closed doors,

@@ -10,8 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnpp_amd.so")
-SOURCES = ["npp_kernels.hip", "npp_render.hip", "npp_capi.cpp", "npp_level.cpp"]
-HEADERS = ["npp_internal.hpp", "npp_level.hpp", "npp_zoo.hpp", os.path.join("..", "..", "include", "npp_amd.h")]
+SOURCES = ["npp_kernels.hip", "npp_render.hip", "npp_reach_kernel.hip", "npp_capi.cpp", "npp_level.cpp", "npp_reach.cpp"]
+HEADERS = ["npp_internal.hpp", "npp_level.hpp", "npp_zoo.hpp", "npp_reach.hpp", "npp_reach_build.hpp", "npp_reach_features.hpp",
+           "npp_reach_tables.inc", os.path.join("..", "..", "include", "npp_amd.h")]
 
 
 def needs_build():
@@ -39,7 +40,8 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     if verbose:
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
     jobs = [("npp_kernels.hip", ["-DNPP_TU=%d" % k], "npp_kernels_tu%d.o" % k) for k in range(4)]
-    jobs += [("npp_render.hip", [], "npp_render.o"), ("npp_capi.cpp", [], "npp_capi.o"), ("npp_level.cpp", [], "npp_level.o")]
+    jobs += [("npp_render.hip", [], "npp_render.o"), ("npp_capi.cpp", [], "npp_capi.o"), ("npp_level.cpp", [], "npp_level.o"),
+             ("npp_reach_kernel.hip", [], "npp_reach_kernel.o"), ("npp_reach.cpp", [], "npp_reach.o")]
     procs = []
     for src, extra, obj in jobs:
         cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)]

@@ -10,6 +10,7 @@
 #include "../../include/npp_amd.h"
 #include "npp_internal.hpp"
 #include "npp_level.hpp"
+#include "npp_reach_build.hpp"
 
 using namespace npp;
 
@@ -41,6 +42,12 @@ struct npp_handle_s {
     uint8_t *d_mask = nullptr;
     unsigned char *d_blob = nullptr;
     uint8_t *d_canvas = nullptr;   // tile-layer coverage canvas of every level (render paths; built on first use)
+    // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
+    ReachHdr *d_rhdr = nullptr;
+    unsigned char *d_rblob = nullptr;
+    uint32_t *d_rkey = nullptr, *s_rkey = nullptr;      // (ninja cell, exit_switch_activated) of the cached vector, 0 = none
+    float *d_rcache = nullptr, *s_rcache = nullptr;     // [n][REACH_DIM + 1]
+    int s_reach = 0;                                    // the snapshot slot holds a reachability cache
     LevelHdr *d_hdr = nullptr;
     int n_words_max = 1;
     uint32_t hot_max = 0;      // largest staged-level size over the loaded set
@@ -207,6 +214,41 @@ int ensure_canvas(npp_handle h) {
     return NPP_OK;
 }
 
+void free_reach(npp_handle h) {
+    hipFree(h->d_rhdr); hipFree(h->d_rblob); hipFree(h->d_rkey); hipFree(h->d_rcache); hipFree(h->s_rkey); hipFree(h->s_rcache);
+    h->d_rhdr = nullptr; h->d_rblob = nullptr; h->d_rkey = nullptr; h->d_rcache = nullptr; h->s_rkey = nullptr; h->s_rcache = nullptr;
+    h->s_reach = 0;
+}
+
+// The reachability tables (npp_reach.cpp) are built the first time the observation is asked for: ~1 ms of host work and
+// ~260 KB of HBM per level, which handles that never ask for it do not pay.
+int ensure_reach(npp_handle h) {
+    if (h->d_rhdr) return NPP_OK;
+    const size_t nl = h->levels.size();
+    std::vector<ReachHdr> hdrs(nl);
+    std::vector<unsigned char> blob;
+    for (size_t i = 0; i < nl; i++) {
+        ReachBuilt R;
+        build_reach(h->levels[i], R);
+        if (!R.hdr.supported)
+            return fail(h, NPP_ERR_UNSUPPORTED, "npp_reachability: level " + std::to_string(i) + ": " + R.note +
+                                                    " (outside the restated part of the reference's reachability code, see DESIGN.md)");
+        pack_reach(R, hdrs[i], blob);
+    }
+    const size_t N = (size_t)h->n;
+    HIP_TRY(h, hipMalloc((void **)&h->d_rblob, blob.size() + 16));
+    HIP_TRY(h, hipMemcpy(h->d_rblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc((void **)&h->d_rkey, sizeof(uint32_t) * N));
+    HIP_TRY(h, hipMemset(h->d_rkey, 0, sizeof(uint32_t) * N));
+    HIP_TRY(h, hipMalloc((void **)&h->d_rcache, sizeof(float) * (REACH_DIM + 1) * N));
+    HIP_TRY(h, hipMemset(h->d_rcache, 0, sizeof(float) * (REACH_DIM + 1) * N));
+    ReachHdr *d = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d, sizeof(ReachHdr) * nl));
+    HIP_TRY(h, hipMemcpy(d, hdrs.data(), sizeof(ReachHdr) * nl, hipMemcpyHostToDevice));
+    h->d_rhdr = d;   // last: marks the tables as complete
+    return NPP_OK;
+}
+
 // `fresh` = the entities are created for the first time since the level was assigned (the state a replay starts from);
 // any later reset is a Simulator.reset(), after which Entity.index no longer starts at 0 (see ZOO_HEAD in npp_internal.hpp)
 int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh, int fast = 0) {
@@ -269,6 +311,7 @@ int npp_destroy(npp_handle h) {
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
+    free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
     return NPP_OK;
@@ -311,6 +354,16 @@ int npp_snapshot(npp_handle h) {
         if (!h->s_zoo) HIP_TRY(h, hipMalloc((void **)&h->s_zoo, sizeof(double) * (size_t)h->zoo_words * N));
         HIP_TRY(h, hipMemcpyAsync(h->s_zoo, h->d_zoo, sizeof(double) * (size_t)h->zoo_words * N, hipMemcpyDeviceToDevice, h->stream));
     }
+    h->s_reach = 0;
+    if (h->d_rkey) {   // the cached reachability vector is part of what the next observation returns
+        if (!h->s_rkey) {
+            HIP_TRY(h, hipMalloc((void **)&h->s_rkey, sizeof(uint32_t) * N));
+            HIP_TRY(h, hipMalloc((void **)&h->s_rcache, sizeof(float) * (REACH_DIM + 1) * N));
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->s_rkey, h->d_rkey, sizeof(uint32_t) * N, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->s_rcache, h->d_rcache, sizeof(float) * (REACH_DIM + 1) * N, hipMemcpyDeviceToDevice, h->stream));
+        h->s_reach = 1;
+    }
     h->s_ovr = h->ovr;
     h->s_gen = h->assign_gen;
     return NPP_OK;
@@ -327,6 +380,8 @@ int npp_restore(npp_handle h, const uint8_t *env_mask) {
         a.reset_mask = h->d_mask;
     }
     HIP_TRY(h, launch_restore(a, h->s_f64, h->s_u32, h->s_ent, h->s_sc, h->d_zoo ? h->s_zoo : nullptr, h->stream));
+    if (h->d_rkey)   // no cache in the snapshot (taken before the first npp_reachability): the restored envs start without one
+        HIP_TRY(h, launch_reach_restore(a, h->s_reach ? h->s_rkey : nullptr, h->s_rcache, h->d_rkey, h->d_rcache, h->stream));
     if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));
     // the restored zoo blocks carry the repositioning flags / coordinates of the snapshot (head words 3..7): the host's
     // view of them (which decides whether the zoo kernels run) is restored with them
@@ -455,6 +510,7 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(h->d_blob); h->d_blob = nullptr;
     hipFree(h->d_canvas); h->d_canvas = nullptr;
+    free_reach(h);
     hipFree(h->d_hdr); h->d_hdr = nullptr;
     hipFree(h->d_ent); h->d_ent = nullptr;
     hipFree(h->d_zoo); h->d_zoo = nullptr;
@@ -512,6 +568,13 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
     plan_geometry(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_env_level, h->env_level.data(), sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
+    if (h->d_rkey) {   // a new level: the env's cached reachability vector belongs to the old one
+        KernelArgs a = base_args(h);
+        HIP_TRY(h, hipMemcpy(h->d_mask, mask.data(), (size_t)h->n, hipMemcpyHostToDevice));
+        a.reset_mask = h->d_mask;
+        HIP_TRY(h, launch_reach_restore(a, nullptr, nullptr, h->d_rkey, h->d_rcache, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     return reset_impl(h, mask.data(), 1);
 }
 
@@ -631,6 +694,17 @@ int npp_switch_states(npp_handle h, float *d_out) {
     ON_DEVICE(h);
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_switch_states(a, d_out, h->stream));
+    return NPP_OK;
+}
+
+int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status) {
+    if (!h || (!d_features && !d_mine_sdf)) return fail(h, NPP_ERR_INVALID, "npp_reachability: bad arguments");
+    if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reachability: no levels loaded");
+    if (h->n_ovr) return fail(h, NPP_ERR_UNSUPPORTED, "npp_reachability: exit switch / door repositioned with npp_set_entity_pos");
+    ON_DEVICE(h);
+    if (int rc = ensure_reach(h)) return rc;
+    KernelArgs a = base_args(h);
+    HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, d_features, d_mine_sdf, d_status, h->stream));
     return NPP_OK;
 }
 

@@ -146,6 +146,13 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
 hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
 hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *d_out, hipStream_t s);
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
+// npp_reach_kernel.hip (tables: npp_reach.hpp)
+struct ReachHdr;
+hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key, float *cache, float *out,
+                        float *sdf_out, int32_t *status, hipStream_t s);
+// envs selected by a.reset_mask (NULL = all): key / cache <- the snapshot's, or "no cached vector" when src_key == NULL
+hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, const float *src_cache, uint32_t *key, float *cache,
+                                hipStream_t s);
 hipError_t launch_tile_tables(hipStream_t s);   // per-device tile gray tables of the player_frame kernel
 hipError_t launch_tile_canvas(const LevelHdr *d_hdr, const unsigned char *d_blob, uint8_t *d_canvas, int n_levels, hipStream_t s);
 

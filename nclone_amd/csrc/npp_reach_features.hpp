@@ -1,0 +1,232 @@
+// npp_reach_features.hpp -- the position-dependent part of the reachability observation: 38 floats from the per-level tables
+// (npp_reach.hpp) and the ninja position.  One function, compiled for the host (CPU parity test through
+// npp_reach_features_host) and for the device (npp_reach_kernel.hip), so both run the same arithmetic.
+//
+// Restates compute_reachability_features_from_graph (graph/reachability/feature_computation.py:197-937) and the parts of
+// CachedPathDistanceCalculator.get_distance / get_geometric_distance (path_distance_calculator.py:847-1230, 1487-1830) and
+// find_ninja_node (pathfinding_utils.py:1331-1497) it goes through on a level-cache hit, INCLUDING what the reference really
+// does rather than what its comments say:
+//   * `spatial_hash.query` does not exist (spatial_hash.py has find_closest / find_all_within_radius), every call raises and
+//     is swallowed, so all node searches are the linear scans over `adjacency` in dict order (tile row, tile column, sub-node);
+//   * the exit switch handed to the feature code is a dict, and `getattr(dict, "active", True)` is always True: the switch
+//     counts as not collected for ever, feature 12 stays 0 and the current goal stays "switch";
+//   * the level cache holds GEOMETRIC distances, so "physics cost / geometric distance" (feature 21) is 1 -> 1/3 after the log
+//     normalisation whenever both exist;
+//   * the directional platform ray cast snaps to multiples of 12 while nodes sit at 6 mod 12: it never finds a node and
+//     features 30-37 are 1.0;
+//   * features 18-19 (mine gradient) look the SDF up on the wrong object and stay 0.
+// Not restated: the cache-miss branch (physics-aware A*, path_distance_calculator.py:1230-1485), taken when the ninja has no
+// node with a cached distance; `status` bit 0 reports it and the distances are treated as unreachable.
+#pragma once
+#include <cmath>
+
+#include "npp_reach.hpp"
+
+namespace npp {
+
+struct ReachTabs {
+    const ReachHdr *H;
+    const unsigned char *blob;
+    NPP_HD const unsigned char *in() const { return blob + H->off_in; }
+    NPP_HD const double *dist(int g) const { return reinterpret_cast<const double *>(blob + H->off_dist) + (long)g * RNODES; }
+    NPP_HD const int16_t *hop(int g) const { return reinterpret_cast<const int16_t *>(blob + H->off_hop) + (long)g * RNODES; }
+    NPP_HD const double *mh(int g) const { return reinterpret_cast<const double *>(blob + H->off_mh) + (long)g * RNODES * 2; }
+    NPP_HD const float *sdf() const { return reinterpret_cast<const float *>(blob + H->off_sdf); }
+    NPP_HD const float *grad() const { return reinterpret_cast<const float *>(blob + H->off_grad); }
+};
+
+// position of a node in the iteration order of the reference's adjacency dict: tiles row-major, then (6,6) (18,6) (6,18) (18,18)
+NPP_HD inline int reach_order_key(int id) {
+    const int i = id / RH, j = id % RH;
+    return (((j >> 1) * 42 + (i >> 1)) << 2) | ((i & 1) | ((j & 1) << 1));
+}
+
+NPP_HD inline double reach_floor(double v) { return floor(v); }
+
+// find_ninja_node (pathfinding_utils.py:1331-1497).  goal_node < 0: no goal node given (closest overlapping node wins);
+// otherwise the overlapping node with the smallest cached distance to goal `g` wins (Euclidean to goal_node when not cached).
+NPP_HD inline int reach_find_ninja_node(const ReachTabs &T, double px, double py, int goal_node, int g) {
+    const double nx = px - 24.0, ny = py - 24.0;
+    const unsigned char *in = T.in();
+    int cand[4], nc = 0;
+    double cd[4];
+    const int i0 = (int)ceil((nx - 10.0 - 6.0) / 12.0), i1 = (int)reach_floor((nx + 10.0 - 6.0) / 12.0);
+    const int j0 = (int)ceil((ny - 10.0 - 6.0) / 12.0), j1 = (int)reach_floor((ny + 10.0 - 6.0) / 12.0);
+    for (int i = i0; i <= i1; i++)
+        for (int j = j0; j <= j1; j++) {
+            if (i < 0 || i >= RW || j < 0 || j >= RH) continue;
+            const int id = i * RH + j;
+            if (!in[id]) continue;
+            const double dx = (6 + 12 * i) - nx, dy = (6 + 12 * j) - ny, d2 = dx * dx + dy * dy;
+            if (d2 <= 100.0 && nc < 4) { cand[nc] = id; cd[nc] = d2; nc++; }
+        }
+    // dict order
+    for (int a = 1; a < nc; a++)
+        for (int b = a; b > 0 && reach_order_key(cand[b]) < reach_order_key(cand[b - 1]); b--) {
+            const int t = cand[b]; cand[b] = cand[b - 1]; cand[b - 1] = t;
+            const double u = cd[b]; cd[b] = cd[b - 1]; cd[b - 1] = u;
+        }
+    if (nc > 0) {
+        if (goal_node >= 0 && nc > 1) {
+            int best = -1;
+            double bd = INFINITY;
+            const double gx = reach_node_x(goal_node), gy = reach_node_y(goal_node);
+            for (int k = 0; k < nc; k++) {
+                double d = T.dist(g)[cand[k]];
+                if (d == INFINITY) {
+                    const double ex = gx - reach_node_x(cand[k]), ey = gy - reach_node_y(cand[k]);
+                    d = sqrt(ex * ex + ey * ey);   // ((gx - nx) ** 2 + (gy - ny) ** 2) ** 0.5 on integers
+                }
+                if (d < bd) { bd = d; best = cand[k]; }
+            }
+            if (best >= 0) return best;
+        }
+        int best = cand[0];
+        double bd = cd[0];
+        for (int k = 1; k < nc; k++)
+            if (cd[k] < bd) { bd = cd[k]; best = cand[k]; }   // stable sort by distance: the first minimum in dict order
+        return best;
+    }
+    // fallback: the first node in dict order with |x + 24 - px| < 24 and |y + 24 - py| < 24
+    int best = -1, bk = 0x7fffffff;
+    const int a0 = (int)reach_floor((nx - 24.0 - 6.0) / 12.0), a1 = (int)ceil((nx + 24.0 - 6.0) / 12.0);
+    const int b0 = (int)reach_floor((ny - 24.0 - 6.0) / 12.0), b1 = (int)ceil((ny + 24.0 - 6.0) / 12.0);
+    for (int i = a0; i <= a1; i++)
+        for (int j = b0; j <= b1; j++) {
+            if (i < 0 || i >= RW || j < 0 || j >= RH) continue;
+            const int id = i * RH + j;
+            if (!in[id]) continue;
+            if (fabs((6 + 12 * i) + 24.0 - px) < 24.0 && fabs((6 + 12 * j) + 24.0 - py) < 24.0) {
+                const int k = reach_order_key(id);
+                if (k < bk) { bk = k; best = id; }
+            }
+        }
+    return best;
+}
+
+// get_distance / get_geometric_distance on the level-cache path (they return the same number there).  g: 0 exit switch,
+// 1 exit door.  Returns +inf when unreachable; sets *miss when the reference would leave the level-cache path.
+NPP_HD inline double reach_goal_distance(const ReachTabs &T, double px, double py, int g, double entity_radius, bool *miss) {
+    const ReachHdr &H = *T.H;
+    const int gx = H.goal_x[g], gy = H.goal_y[g];
+    if (gx == 0 && gy == 0) return INFINITY;
+    const double combined = 10.0 + entity_radius;
+    const double dx = px - gx, dy = py - gy;
+    if (dx * dx + dy * dy <= combined * combined) return 0.0;
+    const int gid = g == 1 ? H.exit_gid : 0;   // which goal's tables the reference reads (goal-id inference, see ReachHdr)
+    const int sn = reach_find_ninja_node(T, px, py, H.goal_node[2 + g], gid);   // goal node of get_distance: thresholds 16 / 22, then 32
+    if (sn < 0) { *miss = true; return INFINITY; }
+    const double cached = T.dist(gid)[sn];
+    if (cached == INFINITY) { *miss = true; return INFINITY; }
+    const int nh = T.hop(gid)[sn];
+    if (nh >= 0) {
+        const double pdx = reach_node_x(nh) - reach_node_x(sn), pdy = reach_node_y(nh) - reach_node_y(sn);
+        // (path_dx ** 2 + path_dy ** 2) ** 0.5: 12 for a cardinal hop, 288 ** 0.5 for a diagonal one (== sqrt(288) under glibc)
+        const double plen = (pdx != 0.0 && pdy != 0.0) ? 16.970562748477139 : 12.0;
+        const double dirx = pdx / plen, diry = pdy / plen;
+        const double ox = px - (reach_node_x(sn) + 24), oy = py - (reach_node_y(sn) + 24);
+        const double projection = ox * dirx + oy * diry;
+        const double t = cached - projection - combined;
+        return t > 0.0 ? t : 0.0;
+    }
+    const double t = cached - combined;
+    return t > 0.0 ? t : 0.0;
+}
+
+NPP_HD inline float reach_clip01(double v) { return (float)(v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v)); }
+
+// out[38]; sdf_out[3] = mine_sdf_features (value, gradient) at the ninja (npp_environment.py mine_sdf_features);
+// returns status: bit 0 = the reference would have run its physics A* fallback here (not restated)
+NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int total_mines, int deadly_mines, float *out, float *sdf_out) {
+    const ReachHdr &H = *T.H;
+    for (int k = 0; k < REACH_DIM; k++) out[k] = 0.f;
+    bool miss = false;
+    out[0] = H.f0;
+    const double area = H.area_scale;
+    double d_sw = INFINITY, d_ex = INFINITY;
+    if (H.sw_valid) d_sw = reach_goal_distance(T, px, py, 0, 6.0, &miss);
+    if (d_sw != INFINITY) out[1] = reach_clip01(1.0 - d_sw / area);
+    else if (H.ex_valid) {   // third priority of the "next objective" ladder: the exit door (no locked-door switches reach here)
+        const double d = reach_goal_distance(T, px, py, 1, 12.0, &miss);
+        if (d != INFINITY) out[1] = reach_clip01(1.0 - d / area);
+    }
+    if (H.ex_valid) d_ex = reach_goal_distance(T, px, py, 1, 12.0, &miss);
+    if (d_ex != INFINITY) out[2] = reach_clip01(1.0 - d_ex / area);
+    out[3] = H.exit_reachable;
+    out[4] = d_sw != INFINITY ? reach_clip01(d_sw / area) : 1.f;
+    out[5] = d_ex != INFINITY ? reach_clip01(d_ex / area) : 1.f;
+    const bool sw_dir = d_sw != INFINITY, ex_dir = d_ex != INFINITY;
+    if (sw_dir) {
+        const double dx = H.goal_x[0] - px, dy = H.goal_y[0] - py, dist = sqrt(dx * dx + dy * dy);
+        if (dist > 0.001) { out[6] = (float)(dx / dist); out[7] = (float)(dy / dist); }
+    }
+    if (ex_dir) {
+        const double dx = H.goal_x[1] - px, dy = H.goal_y[1] - py, dist = sqrt(dx * dx + dy * dy);
+        if (dist > 0.001) { out[8] = (float)(dx / dist); out[9] = (float)(dy / dist); }
+    }
+    out[10] = reach_clip01(total_mines / 10.0);
+    out[11] = total_mines > 0 ? (float)((double)deadly_mines / (double)total_mines) : 0.f;
+    // out[12] = 0: the switch never reads as activated (see the header comment); current goal = "switch"
+    int ninja_node = -1;
+    if (sw_dir) ninja_node = reach_find_ninja_node(T, px, py, -1, 0);
+    if (ninja_node >= 0) {
+        const int nh = T.hop(0)[ninja_node];
+        if (nh >= 0) {
+            const double dx = (reach_node_x(nh) + 24) - px, dy = (reach_node_y(nh) + 24) - py, dist = sqrt(dx * dx + dy * dy);
+            if (dist > 0.001) { out[13] = (float)(dx / dist); out[14] = (float)(dy / dist); }
+        }
+    }
+    // 15-17: waypoints (none without the curriculum machinery)
+    {   // 18-19 stay 0: the reference looks for the mine SDF on `path_calculator.level_cache`, which has no such attribute (it lives
+        // on the calculator itself, path_distance_calculator.py:114), so its gradient branch never runs.  mine_sdf_features is the
+        // separate observation key read straight from the SDF (MineSignedDistanceField.get_features_at_position).
+        int col = (int)(px / 12.0), row = (int)(py / 12.0);
+        col = col < 0 ? 0 : (col > SDF_W - 1 ? SDF_W - 1 : col);
+        row = row < 0 ? 0 : (row > SDF_H - 1 ? SDF_H - 1 : row);
+        float sv = 1.f, gx = 0.f, gy = 0.f;
+        if (H.off_sdf) {
+            sv = T.sdf()[row * SDF_W + col];
+            gx = T.grad()[(row * SDF_W + col) * 2];
+            gy = T.grad()[(row * SDF_W + col) * 2 + 1];
+        }
+        if (sdf_out) { sdf_out[0] = sv; sdf_out[1] = gx; sdf_out[2] = gy; }
+    }
+    if ((out[13] != 0.f || out[14] != 0.f) && sw_dir) {   // 20: the next hop points away from the goal
+        const double gdx = H.goal_x[0] - px, gdy = H.goal_y[0] - py, gd = sqrt(gdx * gdx + gdy * gdy);
+        if (gd > 0.001) {
+            // float32 features times float64 directions: numpy promotes to float64
+            const double al = (double)out[13] * (gdx / gd) + (double)out[14] * (gdy / gd);
+            if (al < -0.3) out[20] = 1.f;
+        }
+    }
+    if (sw_dir && d_sw != INFINITY) {   // 21: log-normalised physics cost / geometric distance (both are the cached geometric one)
+        const double geo = d_sw;
+        if (geo > 0.001) {
+            double ratio = d_sw / geo;
+            ratio = ratio > 0.1 ? ratio : 0.1;
+            out[21] = reach_clip01((log(ratio) + 2.0) / 6.0);
+        }
+    }
+    if (ninja_node >= 0) {   // 22-24: 4-hop look-ahead direction and its alignment with the next hop
+        const double mx = T.mh(0)[ninja_node * 2], my = T.mh(0)[ninja_node * 2 + 1];
+        if (mx == mx) {
+            out[22] = (float)mx; out[23] = (float)my;
+            if (out[13] != 0.f || out[14] != 0.f) {
+                const float curv = out[13] * out[22] + out[14] * out[23];   // float32 arithmetic (numpy float32 scalars)
+                out[24] = (curv + 1.0f) / 2.0f;
+            }
+        }
+    }
+    if (sw_dir && ex_dir)
+        for (int k = 0; k < 4; k++) out[25 + k] = H.exit_path[k];
+    if (sw_dir) {   // 29: ramps to 1 within 50 px of the switch
+        const double dx = H.goal_x[0] - px, dy = H.goal_y[0] - py, d = sqrt(dx * dx + dy * dy);
+        double c = d / 50.0;
+        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+        out[29] = (float)(1.0 - c);
+    }
+    for (int k = 30; k < 38; k++) out[k] = 1.f;
+    return miss ? 1 : 0;
+}
+
+}  // namespace npp

@@ -57,10 +57,14 @@ _FIELDS = {
     "switch_states": ((25,), torch.float32),
     "player_frame": ((84, 84, 1), torch.uint8),
     "global_view": ((176, 100, 1), torch.uint8),
+    "reachability_features": ((38,), torch.float32),
+    "mine_sdf_features": ((3,), torch.float32),
+    "reach_status": ((), torch.int32),
 }
 _ALWAYS = ("game_state", "entity_pos", "reward", "frames", "action_mask", "flags", "terminal_state")
 _PACKED = ("game_state", "entity_pos", "reward", "frames", "action_mask", "flags")
-_OPTIONAL = ("spatial_context", "positions", "work", "switch_states", "player_frame", "global_view")
+_OPTIONAL = ("spatial_context", "positions", "work", "switch_states", "player_frame", "global_view", "reachability_features",
+             "mine_sdf_features", "reach_status")
 
 
 class OutputBlock:
@@ -170,7 +174,7 @@ class NppBatch:
                                     ptr("frames"), None, ptr("spatial_context"), ptr("positions"), ptr("work"))
 
     def enable_outputs(self, *names):
-        """Add optional outputs (spatial_context, positions, work, switch_states, player_frame, global_view); the output
+        """Add optional outputs (spatial_context, positions, work, switch_states, player_frame, global_view, reachability_features, mine_sdf_features, reach_status); the output
         block is re-allocated, so tensors obtained earlier are stale."""
         new = [k for k in names if k not in self._enabled]
         for k in new:
@@ -308,6 +312,16 @@ class NppBatch:
         assert out.dtype == torch.float32 and out.is_cuda and out.numel() == self.n * 25 and out.is_contiguous()
         nat.check(self.h, self.lib.npp_switch_states(self.h, C.c_void_p(out.data_ptr())))
         return out
+
+    def reachability(self):
+        """Fill the block's reachability_features [N, 38] / mine_sdf_features [N, 3] / reach_status [N] (whichever are
+        enabled) from the current state.  Call once per observation: the 38 floats follow the reference's cache rule
+        (recomputed when the ninja's 24-px cell or exit_switch_activated changed since the previous call)."""
+        t = self.out.t
+        ptr = [C.c_void_p(t[k].data_ptr()) if k in t else None for k in ("reachability_features", "mine_sdf_features", "reach_status")]
+        if ptr[0] is None and ptr[1] is None:
+            raise RuntimeError('enable_outputs("reachability_features") and / or "mine_sdf_features" first')
+        nat.check(self.h, self.lib.npp_reachability(self.h, *ptr))
 
     def render_frame(self, env0=0, count=1):
         """uint8 CUDA tensor [count, 600, 1056, 1]: the whole gray frame (the reference's render() array) of some envs."""

@@ -52,7 +52,7 @@ def action_space():
     return Discrete(6)
 
 
-def observation_space(visual=False, spatial_context=False, switch_states=False):
+def observation_space(visual=False, spatial_context=False, switch_states=False, reachability=False):
     spaces = {
         "game_state": Box(-1.0, 1.0, (41,), np.float32),
         "action_mask": Box(0, 1, (6,), np.int8),
@@ -65,4 +65,7 @@ def observation_space(visual=False, spatial_context=False, switch_states=False):
     if visual:
         spaces["player_frame"] = Box(0, 255, (84, 84, 1), np.uint8)
         spaces["global_view"] = Box(0, 255, (176, 100, 1), np.uint8)   # RENDERED_VIEW_HEIGHT x WIDTH (constants.py:18-19)
+    if reachability:   # npp_environment.py observation space: reachability_features (38), mine_sdf_features (3)
+        spaces["reachability_features"] = Box(0.0, 1.0, (38,), np.float32)   # the reference declares [0, 1] (npp_environment.py:236)
+        spaces["mine_sdf_features"] = Box(-1.0, 1.0, (3,), np.float32)
     return Dict(spaces)

@@ -49,7 +49,7 @@ class NppVecEnvironment:
 
     def __init__(self, levels, num_envs, level_ids=None, frame_skip=4, device=0, enable_visual_observations=False,
                  truncation_limit=10000, output="torch", autoreset=True, enable_spatial_context=False,
-                 enable_switch_states=False, fast_reset=True, stream=None):
+                 enable_switch_states=False, fast_reset=True, stream=None, enable_reachability=False):
         assert output in ("torch", "numpy")
         self.num_envs = int(num_envs)
         self.frame_skip = int(frame_skip)
@@ -58,7 +58,8 @@ class NppVecEnvironment:
         self.single_action_space = spaces.action_space()
         self.single_observation_space = spaces.observation_space(self.enable_visual_observations,
                                                                  spatial_context=bool(enable_spatial_context),
-                                                                 switch_states=bool(enable_switch_states))
+                                                                 switch_states=bool(enable_switch_states),
+                                                                 reachability=bool(enable_reachability))
         self.action_space = self.single_action_space
         self.observation_space = self.single_observation_space
         outputs = ["positions"]
@@ -68,6 +69,8 @@ class NppVecEnvironment:
             outputs.append("switch_states")
         if self.enable_visual_observations:
             outputs += ["player_frame", "global_view"]
+        if enable_reachability:   # reachability_features + mine_sdf_features (npp_environment.py observation keys)
+            outputs += ["reachability_features", "mine_sdf_features"]
         # same-level resets are Simulator.fast_reset in the reference's env (npp_environment.py:541-557): the default here
         self._b = NppBatch(self.num_envs, device=device, autoreset=autoreset, outputs=outputs, fast_reset=fast_reset,
                            stream=stream)
@@ -89,6 +92,8 @@ class NppVecEnvironment:
         if "player_frame" in b.out.t:
             b.render_player_frame()
             b.render_global_view()
+        if "reachability_features" in b.out.t:
+            b.reachability()
 
     def _obs(self, src):
         """src: {name: tensor-or-array} (device tensors, or the host views of ONE staged copy)."""
@@ -102,7 +107,7 @@ class NppVecEnvironment:
             "exit_door_x": pos[:, 4], "exit_door_y": pos[:, 5],
             "switch_activated": (src["flags"] & 4) != 0,
         }
-        for k in ("spatial_context", "switch_states", "player_frame", "global_view"):
+        for k in ("spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features"):
             if k in src:
                 obs[k] = src[k]
         return obs
@@ -169,7 +174,8 @@ class NppEnvironment:
     throughput."""
 
     def __init__(self, map_data=None, custom_map_path=None, frame_skip=4, device=0, enable_visual_observations=False,
-                 truncation_limit=10000, fast_reset=True, enable_spatial_context=False, enable_switch_states=False):
+                 truncation_limit=10000, fast_reset=True, enable_spatial_context=False, enable_switch_states=False,
+                 enable_reachability=False):
         if map_data is None:
             if custom_map_path is None:
                 raise ValueError("NppEnvironment needs map_data or custom_map_path")
@@ -179,7 +185,7 @@ class NppEnvironment:
                                     enable_visual_observations=enable_visual_observations,
                                     truncation_limit=truncation_limit, output="numpy", autoreset=False,
                                     fast_reset=fast_reset, enable_spatial_context=enable_spatial_context,
-                                    enable_switch_states=enable_switch_states)
+                                    enable_switch_states=enable_switch_states, enable_reachability=enable_reachability)
         self.action_space = self._v.single_action_space
         self.observation_space = self._v.single_observation_space
         self.frame_skip = frame_skip
