@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NPP_AMD_LIB") or os.path.join(_HERE, "libnpp_amd.so")
 
 NPP_OK = 0
+NPP_ERR_INVALID, NPP_ERR_HIP, NPP_ERR_UNSUPPORTED, NPP_ERR_STATE = 1, 2, 3, 4
 FLAG_AUTORESET = 1
 FLAG_ALLOW_UNSUPPORTED = 2
 FLAG_FRAME_CENTERED = 4

@@ -81,6 +81,7 @@ class NppVecEnvironment:
         self._b.set_truncation_limit(truncation_limit)
         with self._b._ctx():
             self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
+        self._reset_bits = 11 if autoreset else 0
         self._obs_names = ["game_state", "action_mask", "entity_pos", "positions", "flags"] + outputs[1:]
 
     # -- helpers ------------------------------------------------------------------------------------------------
@@ -105,7 +106,9 @@ class NppVecEnvironment:
             # pass-through scalars of the raw observation (observation_processor.py:374-399), unrounded fp64
             "player_x": pos[:, 0], "player_y": pos[:, 1], "switch_x": pos[:, 2], "switch_y": pos[:, 3],
             "exit_door_x": pos[:, 4], "exit_door_y": pos[:, 5],
-            "switch_activated": (src["flags"] & 4) != 0,
+            # flags describe the step that just ran; an env that was auto-reset (terminated / truncated) returns the spawn
+            # observation, whose switch is not yet hit
+            "switch_activated": ((src["flags"] & 4) != 0) & ((src["flags"] & self._reset_bits) == 0),
         }
         for k in ("spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features"):
             if k in src:
