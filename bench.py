@@ -124,6 +124,10 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the "
                                                       "multi-rank path on one GPU together with --device)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal on a one-GPU box)")
+    ap.add_argument("--full-obs", action="store_true",
+                    help="config 5: every Dict observation inside the timed region -- spatial_context (in the step kernel), "
+                         "switch_states, player_frame, global_view, reachability_features + mine_sdf_features; per-kernel times "
+                         "are reported under obs_kernels (levels whose reachability needs the reference's A* search are dropped)")
     ap.add_argument("--workload", default="c0", choices=["c0", "mines", "doors", "zoo", "c3mixed"],
                     help="c0 = config 2 (the headline metric); see the module docstring")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks itself")
@@ -211,6 +215,16 @@ def main():
     n = args.envs_per_gpu
     K, W, P = args.steps, args.warmup, args.preroll
     outputs = ["work"] + (["player_frame"] if args.player_frame else [])
+    dropped = 0
+    if args.full_obs:
+        from nclone_amd.engine import reach_level_info
+
+        keep = [i for i, m in enumerate(levels) if reach_level_info(m)["supported"]]
+        dropped = len(levels) - len(keep)
+        levels, tags = [levels[i] for i in keep], [tags[i] for i in keep]
+        outputs += ["spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features"]
+    STAGES = (("switch_states", lambda: b.switch_states()), ("player_frame", lambda: b.render_player_frame()),
+              ("global_view", lambda: b.render_global_view()), ("reachability", lambda: b.reachability())) if args.full_obs else ()
     b = NppBatch(n, device=local_rank, autoreset=True, outputs=outputs)
     b.load_levels(levels)
     # 64 consecutive envs (one wavefront / workgroup) per level, levels repeated round-robin; with more ranks than one the
@@ -227,11 +241,14 @@ def main():
         b.step(acts[k], FRAME_SKIP, want_terminal=False, work_out=work_row)
         if args.player_frame:
             b.render_player_frame()
+        for _name, fn in STAGES:
+            fn()
 
     def timed(k0, gather=None):
         """K launches from step index k0 on, bracketed by barrier + synchronize; per-launch HIP events on the launch stream."""
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
         mids = [torch.cuda.Event(enable_timing=True) for _ in range(K)] if args.player_frame else None
+        sevs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES))] for _ in range(K)]
         barrier()
         t0 = time.perf_counter()
         evs[0].record(stream)
@@ -240,12 +257,20 @@ def main():
             if mids is not None:
                 mids[k].record(stream)
                 b.render_player_frame()
+            for j, (_name, fn) in enumerate(STAGES):
+                sevs[k][j].record(stream)
+                fn()
             if gather is not None:
                 gather()
             evs[k + 1].record(stream)
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
-        if mids is None:
+        if STAGES:
+            step_us = [evs[k].elapsed_time(sevs[k][0]) * 1e3 for k in range(K)]
+            render_us = None
+            for j, (name, _fn) in enumerate(STAGES):
+                stage_us[name] = [sevs[k][j].elapsed_time(sevs[k][j + 1] if j + 1 < len(STAGES) else evs[k + 1]) * 1e3 for k in range(K)]
+        elif mids is None:
             step_us = [evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
             render_us = None
         else:
@@ -253,6 +278,7 @@ def main():
             render_us = [mids[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
         return dt, step_us, render_us
 
+    stage_us = {}
     for k in range(P + W):
         one(k)
     dt, step_us, render_us = timed(P + W)
@@ -356,8 +382,10 @@ def main():
                      "levels x 64 envs)" + (", player_frame 84x84 rendered every step" if args.player_frame else ", raster off"),
             "c3mixed": "config 4: %d envs/GPU (x n_gpus), curriculum_level=3 mixed map set (%d levels: c0 + mines + 320 generated "
                        "simpler/simple levels) x 64 envs" + (", RCCL gather of the packed obs reported beside" if args.gather_obs else ""),
-            "doors": "config 5 level set: %d envs/GPU, curriculum_level=4 (locked doors / switches, %d levels x 64 envs), "
-                     "game_state obs (reachability: see bench_reachability)",
+            "doors": "config 5: %d envs/GPU, curriculum_level=4 (locked doors / switches, %d levels x 64 envs), "
+                     + ("full Dict obs every step: game_state, action_mask, entity_positions, spatial_context, switch_states, "
+                        "player_frame, global_view, reachability_features, mine_sdf_features (%d level(s) dropped: their "
+                        "reachability needs the reference's physics A* search)" % dropped if args.full_obs else "game_state obs"),
             "zoo": "secondary level set 'zoo': %d envs/GPU on the %d entity-zoo maps x 64 envs",
         }[args.workload] % (n, len(levels))
         tr = committed_traffic("step") or (None, None)
@@ -411,6 +439,11 @@ def main():
                 "launch_us": pr, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * n,
                 "note": "7056 B written + ~0.2 KB read per env; parity of the raster is unpinned (no cairo/cv2 reference frame)",
             }
+        if stage_us:
+            line["obs_kernels"] = {k: percentiles(v) for k, v in stage_us.items()}
+            line["obs_kernels"]["note"] = ("HIP-event time of each observation kernel per step on the launch stream; npp_step includes "
+                                           "spatial_context; reachability = table look-ups for the envs whose (cell, switch) key changed")
+            line["config"]["full_obs"] = True
         if gather_rep is not None:
             line["with_obs_gather"] = gather_rep
         if async_rep is not None:

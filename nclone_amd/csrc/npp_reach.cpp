@@ -267,11 +267,12 @@ void build_reach(const CompiledLevel &L, ReachBuilt &R) {
         else if (kind == EK_EXIT) doors.push_back(s);
         else if (kind == EK_MINE) (type == 1 ? mines1 : mines21).push_back(s);
     }
-    if (switches.size() != 1 || doors.size() != 1) {
+    if (!((switches.size() == 1 && doors.size() == 1) || (switches.empty() && doors.empty()))) {
         // several exits: the feature code takes the LAST switch (nplay_headless.py _sim_exit_switch) while the level cache keys
-        // its goals on the FIRST (level_data_helpers.py:34-51); the mismatch sends the reference into its physics A* branch
+        // its goals on the FIRST (level_data_helpers.py:34-51); the mismatch sends the reference into its physics A* branch.
+        // (No exit at all is fine: every goal-dependent feature keeps its "unreachable" value.)
         H.supported = 0;
-        R.note = "needs exactly one exit switch / door pair";
+        R.note = "needs one exit switch / door pair (or none)";
     }
     const int sw = switches.empty() ? -1 : switches.back(), dr = doors.empty() ? -1 : doors.back();
     if (sw >= 0) { H.goal_x[0] = (int)L.ent_x[sw]; H.goal_y[0] = (int)L.ent_y[sw]; }

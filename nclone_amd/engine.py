@@ -411,6 +411,18 @@ def compile_level_entities(map_data):
     return buf[: n.value].copy()
 
 
+def reach_level_info(map_data):
+    """Host-only: what the reachability table builder makes of one level: {"supported": the level is inside the restated part
+    of the reference's reachability code, "nodes": len(adjacency), "mines": toggle mines, "surface_area": nodes reachable
+    from the spawn (feature scale)}."""
+    L = nat.lib()
+    m = np.ascontiguousarray(np.asarray(map_data, dtype=np.float64))
+    info = np.zeros(16, dtype=np.int32)
+    nat.check(None, L.npp_reach_compile(m.ctypes.data_as(C.POINTER(C.c_double)), len(m), info.ctypes.data_as(C.c_void_p),
+                                        *([None] * 11)))
+    return {"supported": bool(info[0]), "nodes": int(info[1]), "mines": int(info[11]), "surface_area": int(info[13])}
+
+
 def compile_level_zoo(map_data):
     """Host-only: (hor [89, 51], ver [89, 51] grid-edge counters at load, movers [n, 4] = type, x, y, creation order)."""
     lib = nat.lib()

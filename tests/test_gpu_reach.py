@@ -13,22 +13,30 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNSUPPORTED = {"doors:hcorr:door:100053", "mines:hcorr:mines:100025"}
+UNSUPPORTED = {"doors:hcorr:door:100053", "mines:hcorr:mines:100025", "c0:replay:20", "c0:replay:63", "c0:replay:68", "c0:replay:78",
+               "mines:hcorr:mines:100008"}
 OUT = ("positions", "reachability_features", "mine_sdf_features", "reach_status")
 
 
-@pytest.fixture(scope="module")
-def reach():
-    z = np.load(os.path.join(ROOT, "tests", "golden", "reach.npz"))
+def _load(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", name))
     names = bytes(z["names"]).decode().split("\n")
     sup = [k for k, n in enumerate(names) if n not in UNSUPPORTED]
     return z, names, sup
 
 
-def test_reachability_along_reference_rollouts(reach):
+@pytest.fixture(scope="module")
+def reach():
+    return _load("reach.npz")
+
+
+@pytest.mark.parametrize("fixture", ["reach.npz", "reach2.npz"])
+def test_reachability_along_reference_rollouts(fixture):
+    """reach.npz: 41 supported levels (locked doors, mines, exit-only); reach2.npz: 78 more (all 26 entity-zoo maps -- drones,
+    thwumps, doors of every kind, launch pads ... --, 48 of config 4's generated levels)."""
     from nclone_amd.engine import NppBatch
 
-    z, names, sup = reach
+    z, names, sup = _load(fixture)
     n = len(sup)
     b = NppBatch(n, autoreset=True, outputs=OUT, fast_reset=False)   # the fixture resets with NPlayHeadless.reset()
     b.load_levels([z["m%d" % k] for k in sup])
@@ -43,7 +51,7 @@ def test_reachability_along_reference_rollouts(reach):
     ra = np.stack([z["ra%d" % k] for k in sup])      # [n, 300]
     recomputed = int(sum(z["rc%d" % k].sum() for k in sup))
     episodes = int(sum(z["rt%d" % k].sum() for k in sup))
-    assert recomputed > 1800 and episodes > 40
+    assert recomputed > 1800 and episodes > 40 and n >= 41
 
     def check(t):
         h = b.to_host(OUT)
