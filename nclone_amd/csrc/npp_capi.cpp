@@ -42,6 +42,8 @@ struct npp_handle_s {
     uint8_t *d_mask = nullptr;
     unsigned char *d_blob = nullptr;
     uint8_t *d_canvas = nullptr;   // tile-layer coverage canvas of every level (render paths; built on first use)
+    float *d_gv_h = nullptr;       // global_view: per-level horizontal sums / view of the level right after a reset
+    uint8_t *d_gv_v = nullptr;
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
     unsigned char *d_rblob = nullptr;
@@ -214,6 +216,19 @@ int ensure_canvas(npp_handle h) {
     return NPP_OK;
 }
 
+int ensure_gv(npp_handle h) {
+    if (int rc = ensure_canvas(h)) return rc;
+    if (h->d_gv_h) return NPP_OK;
+    const size_t nl = h->levels.size();
+    HIP_TRY(h, hipMalloc((void **)&h->d_gv_v, nl * 176 * 100));
+    float *gh = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&gh, nl * 600 * 100 * sizeof(float)));
+    KernelArgs a = base_args(h);
+    HIP_TRY(h, launch_gv_static(a, (int)nl, gh, h->d_gv_v, h->stream));
+    h->d_gv_h = gh;
+    return NPP_OK;
+}
+
 void free_reach(npp_handle h) {
     hipFree(h->d_rhdr); hipFree(h->d_rblob); hipFree(h->d_rkey); hipFree(h->d_rcache); hipFree(h->s_rkey); hipFree(h->s_rcache);
     h->d_rhdr = nullptr; h->d_rblob = nullptr; h->d_rkey = nullptr; h->d_rcache = nullptr; h->s_rkey = nullptr; h->s_rcache = nullptr;
@@ -311,6 +326,7 @@ int npp_destroy(npp_handle h) {
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
+    hipFree(h->d_gv_h); hipFree(h->d_gv_v);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -510,6 +526,8 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(h->d_blob); h->d_blob = nullptr;
     hipFree(h->d_canvas); h->d_canvas = nullptr;
+    hipFree(h->d_gv_h); h->d_gv_h = nullptr;
+    hipFree(h->d_gv_v); h->d_gv_v = nullptr;
     free_reach(h);
     hipFree(h->d_hdr); h->d_hdr = nullptr;
     hipFree(h->d_ent); h->d_ent = nullptr;
@@ -722,9 +740,9 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_global_view: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_global_view: no levels loaded");
     ON_DEVICE(h);
-    if (int rc = ensure_canvas(h)) return rc;
+    if (int rc = ensure_gv(h)) return rc;
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_global_view(a, d_out, h->stream));
+    HIP_TRY(h, launch_global_view(a, h->d_gv_h, h->d_gv_v, d_out, h->stream));
     return NPP_OK;
 }
 

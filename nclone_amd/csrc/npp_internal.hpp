@@ -143,7 +143,9 @@ hipError_t launch_reset(const KernelArgs &a, hipStream_t s);
 hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint32_t *src_u32, const uint32_t *src_ent,
                           const float *src_sc, const double *src_zoo, hipStream_t s);
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
-hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s);
+hipError_t launch_global_view(const KernelArgs &a, const float *gv_h, const uint8_t *gv_v, uint8_t *d_out, hipStream_t s);
+// per-level static tables of global_view: gv_h f32[n_levels][600][100], gv_v u8[n_levels][176][100] (needs the tile canvas)
+hipError_t launch_gv_static(const KernelArgs &a, int n_levels, float *gv_h, uint8_t *gv_v, hipStream_t s);
 hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *d_out, hipStream_t s);
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
 // npp_reach_kernel.hip (tables: npp_reach.hpp)

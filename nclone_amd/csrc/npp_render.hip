@@ -197,10 +197,16 @@ struct DrawCtx {
     const LevelHdr *H;
     int env;
     float wx0, wy0, wx1, wy1;
+    bool init;   // the level as it stands right after a reset: entity states from the level's init words, no movers, nothing
+                 // repositioned (global_view's per-level static tables)
 };
 
 __device__ inline uint32_t ent_state_of(const KernelArgs &a, int env, int slot) {
     return (a.ent_bits[(size_t)(slot >> 4) * a.n + env] >> ((slot & 15) * 2)) & 3u;
+}
+__device__ inline uint32_t ent_state_ctx(const DrawCtx &c, int slot) {
+    if (c.init) return (reinterpret_cast<const uint32_t *>(c.a->blob + c.H->off_init_words)[slot >> 4] >> ((slot & 15) * 2)) & 3u;
+    return ent_state_of(*c.a, c.env, slot);
 }
 
 __device__ inline bool door_drawable(const DrawCtx &c, uint32_t d, Draw &out) {
@@ -209,7 +215,7 @@ __device__ inline bool door_drawable(const DrawCtx &c, uint32_t d, Draw &out) {
     const uint32_t *meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_ent_meta);
     const double *doors = reinterpret_cast<const double *>(a.blob + H.off_doors);
     const int slot = (int)doors[5 * d + 4];
-    const uint32_t st = ent_state_of(a, c.env, slot), kind = meta[slot] & 15u;
+    const uint32_t st = ent_state_ctx(c, slot), kind = meta[slot] & 15u;
     // segment.active == door closed: locked = switch not collected, regular = bit 1, trap = switch collected
     const bool closed = kind == EK_LOCKED ? (st & 1u) != 0 : (kind == EK_DOOR_REG ? (st & 2u) != 0 : (st & 1u) == 0);
     if (!closed) return false;
@@ -226,7 +232,7 @@ __device__ inline bool entity_drawable(const DrawCtx &c, uint32_t k, Draw &out) 
     const uint16_t *order = reinterpret_cast<const uint16_t *>(a.blob + H.off_raster);
     const uint32_t ref = order[k];
     if (ref & 0x8000u) {   // a mover: position from the env's zoo block
-        if (!(a.zoo && H.has_zoo)) return false;
+        if (c.init || !(a.zoo && H.has_zoo)) return false;
         const double *zb = a.zoo + (size_t)env * a.zoo_words + ZOO_HEAD + (a.zoo_doors + 1) / 2;
         const uint32_t *mov_meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_mov_meta);
         const int m = (int)(ref & 0x7fffu);
@@ -246,7 +252,7 @@ __device__ inline bool entity_drawable(const DrawCtx &c, uint32_t k, Draw &out) 
     const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);
     const int slot = (int)ref;
     float x = (float)ex[slot], y = (float)ey[slot];
-    if (a.zoo && (slot == H.obs_switch || slot == H.obs_door)) {   // npp_set_entity_pos
+    if (!c.init && a.zoo && (slot == H.obs_switch || slot == H.obs_door)) {   // npp_set_entity_pos
         const double *hd = a.zoo + (size_t)env * a.zoo_words;
         const uint32_t ovr = reinterpret_cast<const uint32_t *>(hd + 3)[0];
         if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)hd[4]; y = (float)hd[5]; }
@@ -254,7 +260,7 @@ __device__ inline bool entity_drawable(const DrawCtx &c, uint32_t k, Draw &out) 
     }
     if (x < c.wx0 || x > c.wx1 || y < c.wy0 || y > c.wy1) return false;
     const uint32_t mm = meta[slot], kind = mm & 15u, type = (mm >> 24) & 63u;
-    const uint32_t st = ent_state_of(a, env, slot);
+    const uint32_t st = ent_state_ctx(c, slot);
     if (kind == EK_MINE) {             // always active; radius follows the state
         out = {x, y, st == 0 ? 4.0f : (st == 1 ? 3.5f : 4.5f), 0.f, 0.f,
                type == 1 ? (float)luma(0x9E, 0x21, 0x26) : (float)luma(0xCE, 0x41, 0x46), 0};
@@ -305,7 +311,7 @@ __device__ inline void append_ordered(bool keep, const Draw &d, Draw *out, int c
 // Called by every thread of the workgroup.  On return *s_n drawables sit in out[] (visible to all threads).
 __device__ void build_draw_list(const KernelArgs &a, const LevelHdr &H, int env, double px, double py, float wx0, float wy0,
                                 float wx1, float wy1, Draw *out, int cap, int *s_n, int *s_wc) {
-    DrawCtx c{&a, &H, env, wx0, wy0, wx1, wy1};
+    DrawCtx c{&a, &H, env, wx0, wy0, wx1, wy1, false};
     if (threadIdx.x == 0) *s_n = 0;
     __syncthreads();
     for (uint32_t d0 = 0; d0 < H.n_door; d0 += blockDim.x) {
@@ -455,7 +461,7 @@ __device__ inline void frame_build(FrameLds &L, const KernelArgs &a, const Level
         nd += __popcll(bal);
     };
     if (H.n_door) {   // closed door strokes first (entity_renderer.py:63-97)
-        DrawCtx c{&a, &H, env, wx0, wy0, wx1, wy1};
+        DrawCtx c{&a, &H, env, wx0, wy0, wx1, wy1, false};
         for (uint32_t d0 = 0; d0 < H.n_door; d0 += 64) {
             Draw d = {};
             const uint32_t k = d0 + lane;
@@ -642,10 +648,19 @@ __global__ __launch_bounds__(256, NPP_RENDER_OCC) void npp_render_kernel(KernelA
 // INTER_AREA) of the (600 rows x 1056 columns) gray frame.  The reference's constants are swapped (constants.py:18-19:
 // "100 / 6", "1056 / 6"), so the frame is squashed anisotropically: 600 rows -> 176 (x 3.409) and 1056 columns -> 100
 // (x 10.56).  Reproduced as is.  INTER_AREA with a non-integer factor is the area-weighted mean of the source pixels under
-// each destination pixel (OpenCV resizeArea: float weights from computeResizeAreaTab, rounded to nearest on store).
-// One workgroup per env: the draw list of the whole canvas is built ONCE; then two output rows per pass (128 lanes each, one
-// output column per lane), each half first compacting the drawables that touch its rows' source band into an LDS index list.
-constexpr int GV_ROWS = 176, GV_COLS = 100, GV_DRAW = 224;
+// each destination pixel, accumulated the way OpenCV's resizeArea does it: per source row y the horizontal sums
+// hs[y][c] = sum_x wx * pixel (x ascending, float), then acc[r][c] = sum_y wy * hs[y][c] (y ascending), rounded to nearest.
+//
+// 633 600 source pixels per env and step is what the round-2 profile of config 5 showed this kernel spending 20 ms on (98 %
+// of the step).  Almost all of them are the same every step: the tile layer never changes and an entity changes its picture
+// only when its state does.  So the level's picture right after a reset is reduced ONCE per level (hs: f32[600][100], the
+// final view: u8[176][100]; built with the same pixel function), and per env and step only the destination cells whose
+// source rectangle meets a "dirty box" are recomputed: the ninja, every mover, every entity whose drawable differs from the
+// one it had after the reset (old and new extent), every repositioned entity.  Inside a dirty cell the source rows no dirty
+// box touches take their hs from the level table; the others are re-summed pixel by pixel over the current draw list.
+// Because the tables hold exactly the partial sums the full computation would produce, the result is bit-identical to
+// reducing the whole frame (tests/test_gpu_render.py compares both).
+constexpr int GV_ROWS = 176, GV_COLS = 100, GV_DRAW = 224, GV_CELLS = GV_ROWS * GV_COLS;
 
 // OpenCV computeResizeAreaTab for one destination index: source range [s1 - (head > 0), s2 + (tail > 0)) with weights
 __device__ inline void area_tab(int d, float scale, int ssize, int &s1, int &s2, float &whead, float &wmid, float &wtail) {
@@ -660,85 +675,217 @@ __device__ inline void area_tab(int d, float scale, int ssize, int &s1, int &s2,
     wtail = (f2 - s2 > 1e-3f) ? fminf(fminf(f2 - s2, 1.f), cell) / cell : 0.f;
 }
 
-__global__ __launch_bounds__(256) void npp_global_view_kernel(KernelArgs a, uint8_t *out) {
+struct AreaTab { int s1, s2, a, b; float wh, wm, wt; };   // source indices [a, b), weights head / middle / tail
+__device__ inline AreaTab gv_col_tab(int c) {
+    AreaTab t;
+    area_tab(c, 1056.f / GV_COLS, 1056, t.s1, t.s2, t.wh, t.wm, t.wt);
+    t.a = t.wh > 0.f ? t.s1 - 1 : t.s1; t.b = t.wt > 0.f ? t.s2 + 1 : t.s2;
+    return t;
+}
+__device__ inline AreaTab gv_row_tab(int r) {
+    AreaTab t;
+    area_tab(r, 600.f / GV_ROWS, 600, t.s1, t.s2, t.wh, t.wm, t.wt);
+    t.a = t.wh > 0.f ? t.s1 - 1 : t.s1; t.b = t.wt > 0.f ? t.s2 + 1 : t.s2;
+    return t;
+}
+__device__ inline float tab_w(const AreaTab &t, int s) { return s < t.s1 ? t.wh : (s < t.s2 ? t.wm : t.wt); }
+
+// horizontal sum of one source row under destination column tab `tx`, over the drawables near[0 .. nn)
+__device__ inline float gv_hsum(const Draw *draw, const int *near, int nn, const uint8_t *crow, int y, const AreaTab &tx) {
+    float hs = 0.f;
+    for (int x = tx.a; x < tx.b; x++) {
+        float eg = 0.f, ea = 0.f;
+        for (int q = 0; q < nn; q++) {
+            const Draw &d = draw[near[q]];
+            const int cnt = draw_cover(d, x, y);
+            if (cnt) {
+                float cov = cnt * (1.f / 16.f);
+                eg = eg * (1.f - cov) + d.gray * cov;
+                ea = ea * (1.f - cov) + cov;
+            }
+        }
+        hs += tab_w(tx, x) * (float)composite(eg, ea, crow[x]);
+    }
+    return hs;
+}
+
+// per-level static tables, pass 1: hs of the level's picture right after a reset.  Grid (600 source rows, levels).
+__global__ __launch_bounds__(128) void npp_gv_static_h_kernel(KernelArgs a, float *gv_h) {
     __shared__ Draw s_draw[GV_DRAW];
     __shared__ int s_n;
-    __shared__ int s_wc[4];
-    __shared__ unsigned char s_row[2][GV_DRAW];   // per half: indices of the drawables touching its source band, in draw order
-    __shared__ int s_rown[2];
+    __shared__ int s_wc[2];
+    const int y = blockIdx.x, lvl = blockIdx.y;
+    const LevelHdr &H = a.hdr[lvl];
+    DrawCtx c{&a, &H, 0, -16.f, y - 16.f, 1056.f + 16.f, y + 1 + 16.f, true};
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t d0 = 0; d0 < H.n_door; d0 += blockDim.x) {
+        Draw d = {};
+        const uint32_t k = d0 + threadIdx.x;
+        const bool keep = k < H.n_door && door_drawable(c, k, d);
+        append_ordered(keep, d, s_draw, GV_DRAW, &s_n, s_wc);
+    }
+    const uint32_t n_draw = H.n_ent + H.n_mov;
+    for (uint32_t k0 = 0; k0 < n_draw; k0 += blockDim.x) {
+        Draw d = {};
+        const uint32_t k = k0 + threadIdx.x;
+        const bool keep = k < n_draw && entity_drawable(c, k, d);
+        append_ordered(keep, d, s_draw, GV_DRAW, &s_n, s_wc);
+    }
+    const int col = threadIdx.x;
+    if (col >= GV_COLS) return;
+    const AreaTab tx = gv_col_tab(col);
+    int near[24], nn = 0;
+    for (int k = 0; k < s_n; k++) {
+        float cx, cy, ex, ey;
+        draw_extent(s_draw[k], cx, cy, ex, ey);
+        if (cx + ex >= tx.a && cx - ex <= tx.b && cy + ey >= y && cy - ey <= y + 1 && nn < 24) near[nn++] = k;
+    }
+    const uint8_t *crow = a.tile_canvas + ((size_t)lvl * 600 + y) * 1056;
+    gv_h[((size_t)lvl * 600 + y) * GV_COLS + col] = gv_hsum(s_draw, near, nn, crow, y, tx);
+}
+
+// pass 2: the level's view from its hs table.  Grid (176 destination rows, levels).
+__global__ __launch_bounds__(128) void npp_gv_static_v_kernel(const float *gv_h, uint8_t *gv_v) {
+    const int r = blockIdx.x, lvl = blockIdx.y, col = threadIdx.x;
+    if (col >= GV_COLS) return;
+    const AreaTab ty = gv_row_tab(r);
+    float acc = 0.f;
+    for (int y = ty.a; y < ty.b; y++) acc += tab_w(ty, y) * gv_h[((size_t)lvl * 600 + y) * GV_COLS + col];
+    gv_v[((size_t)lvl * GV_ROWS + r) * GV_COLS + col] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
+}
+
+struct GvLds {
+    Draw draw[GV_DRAW];
+    float4 box[2 * GV_DRAW + 2];            // dirty boxes: x0, y0, x1, y1 (canvas pixels, conservative)
+    uint32_t dirty[(GV_CELLS + 31) / 32];   // destination cells to recompute
+    unsigned short queue[GV_CELLS];
+    int nd, nb, nq;
+    int wc[4];
+};
+
+__device__ inline bool draw_differs(const Draw &p, const Draw &q) {
+    return p.x != q.x || p.y != q.y || p.r != q.r || p.x2 != q.x2 || p.y2 != q.y2 || p.gray != q.gray || p.shape != q.shape;
+}
+__device__ inline void gv_push_box(GvLds &L, const Draw &d) {
+    float cx, cy, ex, ey;
+    draw_extent(d, cx, cy, ex, ey);
+    const int i = atomicAdd(&L.nb, 1);
+    if (i < 2 * GV_DRAW + 2) L.box[i] = make_float4(cx - ex, cy - ey, cx + ex, cy + ey);
+}
+
+__global__ __launch_bounds__(256) void npp_global_view_kernel(KernelArgs a, const float *gv_h, const uint8_t *gv_v, uint8_t *out) {
+    __shared__ GvLds L;
     const int env = blockIdx.x;
     if (env >= a.n) return;
-    const int lvl = a.env_level[env];
+    const int lvl = __builtin_amdgcn_readfirstlane(a.env_level[env]);
     const LevelHdr &H = a.hdr[lvl];
     const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
-    build_draw_list(a, H, env, px, py, -16.f, -16.f, 1056.f + 16.f, 600.f + 16.f, s_draw, GV_DRAW, &s_n, s_wc);
-    const int nd = s_n;
+    for (int i = threadIdx.x; i < (GV_CELLS + 31) / 32; i += blockDim.x) L.dirty[i] = 0u;
+    if (threadIdx.x == 0) { L.nd = 0; L.nb = 0; L.nq = 0; }
+    // the level's view, to be patched below (dword copy: 17 600 B)
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(gv_v + (size_t)lvl * GV_CELLS);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
+        for (int i = threadIdx.x; i < GV_CELLS / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    // ---- current draw list (draw order) + dirty boxes
+    DrawCtx cc{&a, &H, env, -16.f, -16.f, 1056.f + 16.f, 600.f + 16.f, false};
+    DrawCtx ci = cc;
+    ci.init = true;
+    const uint32_t n_draw = H.n_ent + H.n_mov;
+    for (uint32_t d0 = 0; d0 < H.n_door; d0 += blockDim.x) {
+        Draw d = {}, di = {};
+        const uint32_t k = d0 + threadIdx.x;
+        const bool kc = k < H.n_door && door_drawable(cc, k, d);
+        const bool ki = k < H.n_door && door_drawable(ci, k, di);
+        if (kc != ki || (kc && draw_differs(d, di))) {
+            if (kc) gv_push_box(L, d);
+            if (ki) gv_push_box(L, di);
+        }
+        append_ordered(kc, d, L.draw, GV_DRAW, &L.nd, L.wc);
+    }
+    for (uint32_t k0 = 0; k0 < n_draw; k0 += blockDim.x) {
+        Draw d = {}, di = {};
+        const uint32_t k = k0 + threadIdx.x;
+        const bool kc = k < n_draw && entity_drawable(cc, k, d);
+        const bool ki = k < n_draw && entity_drawable(ci, k, di);
+        if (kc != ki || (kc && draw_differs(d, di))) {
+            if (kc) gv_push_box(L, d);
+            if (ki) gv_push_box(L, di);
+        }
+        append_ordered(kc, d, L.draw, GV_DRAW, &L.nd, L.wc);
+    }
+    if (threadIdx.x == 0) {   // the ninja, drawn last
+        const Draw nj = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};
+        if (L.nd < GV_DRAW) L.draw[L.nd++] = nj;
+        gv_push_box(L, nj);
+    }
+    __syncthreads();
+    const int nd = L.nd, nb = L.nb < 2 * GV_DRAW + 2 ? L.nb : 2 * GV_DRAW + 2;
+    // ---- destination cells under the dirty boxes
+    const float sx = 1056.f / GV_COLS, sy = 600.f / GV_ROWS;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        const float4 bx = L.box[b];
+        int c0 = (int)floorf(bx.x / sx) - 1, c1 = (int)floorf(bx.z / sx) + 1, r0 = (int)floorf(bx.y / sy) - 1, r1 = (int)floorf(bx.w / sy) + 1;
+        c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
+        c1 = c1 > GV_COLS - 1 ? GV_COLS - 1 : c1; r1 = r1 > GV_ROWS - 1 ? GV_ROWS - 1 : r1;
+        for (int r = r0; r <= r1; r++) {
+            const AreaTab ty = gv_row_tab(r);
+            if (!(bx.w >= ty.a && bx.y <= ty.b)) continue;
+            for (int c = c0; c <= c1; c++) {
+                const AreaTab tx = gv_col_tab(c);
+                if (!(bx.z >= tx.a && bx.x <= tx.b)) continue;
+                const int cell = r * GV_COLS + c;
+                atomicOr(&L.dirty[cell >> 5], 1u << (cell & 31));
+            }
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < (GV_CELLS + 31) / 32; w += blockDim.x) {
+        uint32_t m = L.dirty[w];
+        while (m) {
+            const int bit = __builtin_ctz(m);
+            m &= m - 1;
+            L.queue[atomicAdd(&L.nq, 1)] = (unsigned short)(w * 32 + bit);
+        }
+    }
+    __syncthreads();
+    // ---- recompute the dirty cells, one per lane
+    const int nq = L.nq;
     const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
-    const float sy = 600.f / GV_ROWS, sx = 1056.f / GV_COLS;
-    const int half = threadIdx.x >> 7, c = threadIdx.x & 127, hw = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
-    int x1 = 0, x2 = 0;
-    float wxh = 0.f, wxm = 0.f, wxt = 0.f;
-    if (c < GV_COLS) area_tab(c, sx, 1056, x1, x2, wxh, wxm, wxt);
-    const int xa = wxh > 0.f ? x1 - 1 : x1, xb = wxt > 0.f ? x2 + 1 : x2;
-    for (int r0 = 0; r0 < GV_ROWS; r0 += 2) {
-        const int r = r0 + half;
-        int y1, y2;
-        float wyh, wym, wyt;
-        area_tab(r, sy, 600, y1, y2, wyh, wym, wyt);
-        const int ya = wyh > 0.f ? y1 - 1 : y1, yb = wyt > 0.f ? y2 + 1 : y2;   // canvas rows [ya, yb)
-        // ordered compaction of the band's drawables (each half = 2 wavefronts = 128 candidates per pass)
-        if (c == 0) s_rown[half] = 0;
-        __syncthreads();
-        for (int k0 = 0; k0 < nd; k0 += 128) {
-            const int k = k0 + c;
-            bool keep = false;
-            if (k < nd) {
-                float cx, cy, ex, ey;
-                draw_extent(s_draw[k], cx, cy, ex, ey);
-                keep = cy + ey >= ya && cy - ey <= yb;
-            }
-            const unsigned long long bal = __ballot(keep);
-            const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wc[half * 2 + hw] = __popcll(bal);
-            __syncthreads();
-            const int base = s_rown[half] + (hw ? s_wc[half * 2] : 0);
-            if (keep) s_row[half][base + prefix] = (unsigned char)k;
-            __syncthreads();
-            if (c == 0) s_rown[half] += s_wc[half * 2] + s_wc[half * 2 + 1];
-            __syncthreads();
+    const float *hrow = gv_h + (size_t)lvl * 600 * GV_COLS;
+    for (int qi = threadIdx.x; qi < nq; qi += blockDim.x) {
+        const int cell = L.queue[qi], r = cell / GV_COLS, c = cell - r * GV_COLS;
+        const AreaTab tx = gv_col_tab(c), ty = gv_row_tab(r);
+        int near[24], nn = 0;
+        for (int k = 0; k < nd; k++) {
+            float cx, cy, ex, ey;
+            draw_extent(L.draw[k], cx, cy, ex, ey);
+            if (cx + ex >= tx.a && cx - ex <= tx.b && cy + ey >= ty.a && cy - ey <= ty.b && nn < 24) near[nn++] = k;
         }
-        const int nrow = s_rown[half];
-        if (c < GV_COLS) {
-            // drawables near this destination pixel's source rectangle
-            int near[24], nn = 0;
-            for (int q = 0; q < nrow; q++) {
-                const int k = s_row[half][q];
-                float cx, cy, ex, ey;
-                draw_extent(s_draw[k], cx, cy, ex, ey);
-                if (cx + ex >= xa && cx - ex <= xb && nn < 24) near[nn++] = k;
+        unsigned short nbox[16];
+        int nbx = 0;
+        bool all_rows = false;   // more boxes than the list holds: recompute every row of the cell
+        for (int b = 0; b < nb; b++) {
+            const float4 bx = L.box[b];
+            if (bx.z >= tx.a && bx.x <= tx.b && bx.w >= ty.a && bx.y <= ty.b) {
+                if (nbx < 16) nbox[nbx++] = (unsigned short)b;
+                else all_rows = true;
             }
-            float acc = 0.f;
-            for (int y = ya; y < yb; y++) {
-                const float wy = (y < y1) ? wyh : (y < y2 ? wym : wyt);
-                const uint8_t *crow = canvas + (size_t)y * 1056;
-                for (int x = xa; x < xb; x++) {
-                    const float wx = (x < x1) ? wxh : (x < x2 ? wxm : wxt);
-                    float eg = 0.f, ea = 0.f;
-                    for (int q = 0; q < nn; q++) {
-                        const Draw &d = s_draw[near[q]];
-                        const int cnt = draw_cover(d, x, y);
-                        if (cnt) {
-                            float cov = cnt * (1.f / 16.f);
-                            eg = eg * (1.f - cov) + d.gray * cov;
-                            ea = ea * (1.f - cov) + cov;
-                        }
-                    }
-                    acc += wy * wx * (float)composite(eg, ea, crow[x]);
-                }
-            }
-            out[((size_t)env * GV_ROWS + r) * GV_COLS + c] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
         }
-        __syncthreads();
+        float acc = 0.f;
+        for (int y = ty.a; y < ty.b; y++) {
+            bool touched = all_rows;
+            for (int q = 0; q < nbx && !touched; q++) {
+                const float4 bx = L.box[nbox[q]];
+                touched = bx.w >= y && bx.y <= y + 1;
+            }
+            const float hs = touched ? gv_hsum(L.draw, near, nn, canvas + (size_t)y * 1056, y, tx) : hrow[(size_t)y * GV_COLS + c];
+            acc += tab_w(ty, y) * hs;
+        }
+        out[(size_t)env * GV_CELLS + cell] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
     }
 }
 
@@ -801,8 +948,14 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_global_view(const KernelArgs &a, uint8_t *d_out, hipStream_t s) {
-    hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n), dim3(256), 0, s, a, d_out);
+hipError_t launch_global_view(const KernelArgs &a, const float *gv_h, const uint8_t *gv_v, uint8_t *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n), dim3(256), 0, s, a, gv_h, gv_v, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_gv_static(const KernelArgs &a, int n_levels, float *gv_h, uint8_t *gv_v, hipStream_t s) {
+    hipLaunchKernelGGL(npp_gv_static_h_kernel, dim3(600, n_levels), dim3(128), 0, s, a, gv_h);
+    hipLaunchKernelGGL(npp_gv_static_v_kernel, dim3(GV_ROWS, n_levels), dim3(128), 0, s, gv_h, gv_v);
     return hipGetLastError();
 }
 

@@ -343,20 +343,17 @@ def global_view(tiles, rows, px, py, ss=4):
     sy, sx = np.float32(600.0 / 176), np.float32(1056.0 / 100)
     wy = [_area_tab(r, sy, 600) for r in range(176)]
     wx = [_area_tab(q, sx, 1056) for q in range(100)]
+    # OpenCV's resizeArea order: per source row the horizontal sums (x ascending), then the vertical accumulation (y ascending)
+    hs = np.zeros((600, 100), dtype=np.float32)
+    he = np.zeros((600, 100), dtype=np.float32)
+    for q in range(100):
+        for (s_, w) in wx[q]:
+            hs[:, q] += np.float32(w) * c[:, s_]
+            he[:, q] += np.float32(w) * e[:, s_]
     out = np.zeros((176, 100), dtype=np.float32)
     ef = np.zeros((176, 100), dtype=np.float32)
     for r in range(176):
-        rowmix = np.zeros(1056, dtype=np.float32)
-        emix = np.zeros(1056, dtype=np.float32)
-        for (s, w) in wy[r]:
-            rowmix += np.float32(w) * c[s]
-            emix += np.float32(w) * e[s]
-        for q in range(100):
-            acc = np.float32(0)
-            ea = np.float32(0)
-            for (s, w) in wx[q]:
-                acc += np.float32(w) * rowmix[s]
-                ea += np.float32(w) * emix[s]
-            out[r, q] = acc
-            ef[r, q] = ea
+        for (s_, w) in wy[r]:
+            out[r] += np.float32(w) * hs[s_]
+            ef[r] += np.float32(w) * he[s_]
     return np.clip(np.rint(out), 0, 255).astype(np.uint8), ef

@@ -128,6 +128,70 @@ def test_global_view(golden, oracle_mod):
         assert ref.std() > 10       # a real picture, not a constant
 
 
+def _area_tabs(n_dst, scale, ssize):
+    """Padded (index, weight) tables of OpenCV's computeResizeAreaTab (tests/raster_ref._area_tab), float32."""
+    from tests.raster_ref import _area_tab
+
+    tabs = [_area_tab(d, np.float32(scale), ssize) for d in range(n_dst)]
+    m = max(len(t) for t in tabs)
+    idx = np.zeros((n_dst, m), dtype=np.int64)
+    w = np.zeros((n_dst, m), dtype=np.float32)
+    for d, t in enumerate(tabs):
+        for j, (s_, ww) in enumerate(t):
+            idx[d, j], w[d, j] = s_, ww
+    return torch.from_numpy(idx).cuda(), torch.from_numpy(w).cuda()
+
+
+def _reduce_frame(frame, xtab, ytab):
+    """cv2.resize(frame, (100, 176), INTER_AREA) of one [600, 1056] float32 frame in OpenCV's accumulation order; padding
+    entries carry weight 0 and add exactly 0."""
+    (ix, wx), (iy, wy) = xtab, ytab
+    hs = torch.zeros((600, 100), dtype=torch.float32, device="cuda")
+    for j in range(ix.shape[1]):
+        hs = hs + wx[:, j][None, :] * frame[:, ix[:, j]]
+    acc = torch.zeros((176, 100), dtype=torch.float32, device="cuda")
+    for j in range(iy.shape[1]):
+        acc = acc + wy[:, j][:, None] * hs[iy[:, j]]
+    return torch.clamp(torch.round(acc), 0, 255).to(torch.uint8)
+
+
+def test_global_view_equals_reduction_of_the_whole_frame(golden, oracle_mod):
+    """The global_view kernel patches a per-level table (the level's view right after a reset) in the destination cells that
+    something dynamic can touch.  It must equal, bit for bit, the area reduction of the WHOLE rendered frame of the same env
+    (npp_render_frame, every one of the 633 600 pixels through the same pixel function) -- on zoo levels after 40 and after
+    400 steps (moved drones / thwumps, collected gold, opened doors, toggled mines, dead and respawned ninjas)."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import door_levels, mine_levels
+
+    c, z = golden.z("corpus"), golden.z("zoo")
+    levels = [c["m%d" % int(i)].astype(np.float64) for i in z["idx"]] + door_levels()[0][:8] + mine_levels()[0][:14]
+    n = len(levels)
+    b = NppBatch(n, autoreset=True)
+    b.load_levels(levels)
+    b.assign_levels(np.arange(n))
+    warm = torch.from_numpy(np.random.default_rng(76).integers(0, 6, size=(40, n)).astype(np.uint8)).cuda()
+    for t in range(40):
+        b.step(warm[t])
+    xtab, ytab = _area_tabs(100, 1056.0 / 100, 1056), _area_tabs(176, 600.0 / 176, 600)
+    acts = torch.from_numpy(np.random.default_rng(77).integers(0, 6, size=(360, b.n)).astype(np.uint8)).cuda()
+    changed_cells = 0
+    for phase in range(2):
+        out = torch.zeros((b.n, 176, 100), dtype=torch.uint8, device="cuda")
+        b.render_global_view(out)
+        for e in range(b.n):
+            frame = b.render_frame(e, 1)[0, :, :, 0].float()
+            ref = _reduce_frame(frame, xtab, ytab)
+            assert torch.equal(out[e], ref), (phase, e, int((out[e] != ref).sum()))
+        if phase == 0:
+            first = out.clone()
+            for t in range(acts.shape[0]):
+                b.step(acts[t])
+        else:
+            changed_cells = int((out != first).sum())
+    assert changed_cells > 100   # the picture did change between the two phases
+    b.close()
+
+
 def test_full_frame_consistent_with_player_frame_and_reference_raster(golden, oracle_mod):
     """render(): the whole 600 x 1056 frame.  Its crop around the player must BE the player_frame (same pixel function), and
     a band of it matches the numpy rasteriser under the usual tolerance."""
