@@ -1,6 +1,7 @@
 // npp_capi.cpp -- the C ABI declared in include/npp_amd.h: handle management, level upload, launches.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,8 +43,8 @@ struct npp_handle_s {
     uint8_t *d_mask = nullptr;
     unsigned char *d_blob = nullptr;
     uint8_t *d_canvas = nullptr;   // tile-layer coverage canvas of every level (render paths; built on first use)
-    float *d_gv_h = nullptr;       // global_view: per-level horizontal sums / view of the level right after a reset
-    uint8_t *d_gv_v = nullptr;
+    float *d_gv_h = nullptr;       // global_view: per-level picture / horizontal sums / view of the level right after a reset
+    uint8_t *d_gv_v = nullptr, *d_gv_p = nullptr;
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
     unsigned char *d_rblob = nullptr;
@@ -221,10 +222,11 @@ int ensure_gv(npp_handle h) {
     if (h->d_gv_h) return NPP_OK;
     const size_t nl = h->levels.size();
     HIP_TRY(h, hipMalloc((void **)&h->d_gv_v, nl * 176 * 100));
+    HIP_TRY(h, hipMalloc((void **)&h->d_gv_p, nl * 600 * 1056 + 16));   // + 16: row slices are read as four aligned dwords
     float *gh = nullptr;
     HIP_TRY(h, hipMalloc((void **)&gh, nl * 600 * 100 * sizeof(float)));
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_gv_static(a, (int)nl, gh, h->d_gv_v, h->stream));
+    HIP_TRY(h, launch_gv_static(a, (int)nl, h->d_gv_p, gh, h->d_gv_v, h->stream));
     h->d_gv_h = gh;
     return NPP_OK;
 }
@@ -326,7 +328,7 @@ int npp_destroy(npp_handle h) {
     hipDeviceSynchronize();
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
-    hipFree(h->d_gv_h); hipFree(h->d_gv_v);
+    hipFree(h->d_gv_h); hipFree(h->d_gv_v); hipFree(h->d_gv_p);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -528,6 +530,7 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
     hipFree(h->d_canvas); h->d_canvas = nullptr;
     hipFree(h->d_gv_h); h->d_gv_h = nullptr;
     hipFree(h->d_gv_v); h->d_gv_v = nullptr;
+    hipFree(h->d_gv_p); h->d_gv_p = nullptr;
     free_reach(h);
     hipFree(h->d_hdr); h->d_hdr = nullptr;
     hipFree(h->d_ent); h->d_ent = nullptr;
@@ -742,7 +745,9 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     ON_DEVICE(h);
     if (int rc = ensure_gv(h)) return rc;
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_global_view(a, h->d_gv_h, h->d_gv_v, d_out, h->stream));
+    int max_records = 0;
+    for (const LevelHdr &lh : h->hdrs) max_records = std::max(max_records, (int)(lh.n_door + lh.n_ent + lh.n_mov));
+    HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->stream));
     return NPP_OK;
 }
 

@@ -143,9 +143,12 @@ hipError_t launch_reset(const KernelArgs &a, hipStream_t s);
 hipError_t launch_restore(const KernelArgs &a, const double *src_f64, const uint32_t *src_u32, const uint32_t *src_ent,
                           const float *src_sc, const double *src_zoo, hipStream_t s);
 hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipStream_t s);
-hipError_t launch_global_view(const KernelArgs &a, const float *gv_h, const uint8_t *gv_v, uint8_t *d_out, hipStream_t s);
-// per-level static tables of global_view: gv_h f32[n_levels][600][100], gv_v u8[n_levels][176][100] (needs the tile canvas)
-hipError_t launch_gv_static(const KernelArgs &a, int n_levels, float *gv_h, uint8_t *gv_v, hipStream_t s);
+// max_records: the largest number of draw records (closed-door strokes + entities + movers) of a loaded level; sizes the LDS
+hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_t *gv_p, const float *gv_h, const uint8_t *gv_v,
+                              uint8_t *d_out, hipStream_t s);
+// per-level static tables of global_view (the level right after a reset; needs the tile canvas): gv_p u8[n_levels][600][1056]
+// (+ 16 bytes) picture, gv_h f32[n_levels][600][100] horizontal sums, gv_v u8[n_levels][176][100] view
+hipError_t launch_gv_static(const KernelArgs &a, int n_levels, uint8_t *gv_p, float *gv_h, uint8_t *gv_v, hipStream_t s);
 hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *d_out, hipStream_t s);
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
 // npp_reach_kernel.hip (tables: npp_reach.hpp)

@@ -688,32 +688,23 @@ __device__ inline AreaTab gv_row_tab(int r) {
     t.a = t.wh > 0.f ? t.s1 - 1 : t.s1; t.b = t.wt > 0.f ? t.s2 + 1 : t.s2;
     return t;
 }
-__device__ inline float tab_w(const AreaTab &t, int s) { return s < t.s1 ? t.wh : (s < t.s2 ? t.wm : t.wt); }
-
-// horizontal sum of one source row under destination column tab `tx`, over the drawables near[0 .. nn)
-__device__ inline float gv_hsum(const Draw *draw, const int *near, int nn, const uint8_t *crow, int y, const AreaTab &tx) {
-    float hs = 0.f;
-    for (int x = tx.a; x < tx.b; x++) {
-        float eg = 0.f, ea = 0.f;
-        for (int q = 0; q < nn; q++) {
-            const Draw &d = draw[near[q]];
-            const int cnt = draw_cover(d, x, y);
-            if (cnt) {
-                float cov = cnt * (1.f / 16.f);
-                eg = eg * (1.f - cov) + d.gray * cov;
-                ea = ea * (1.f - cov) + cov;
-            }
-        }
-        hs += tab_w(tx, x) * (float)composite(eg, ea, crow[x]);
-    }
-    return hs;
+// weight of source index s.  Written on scalars: selecting among the struct's fields by value made the compiler spill the
+// struct and index it in scratch memory (a dependent scratch load per pixel).
+__device__ inline float tab_w3(int s, int s1, int s2, float wh, float wm, float wt) {
+    float w = wm;
+    w = s < s1 ? wh : w;
+    w = s >= s2 ? wt : w;
+    return w;
 }
+__device__ inline float tab_w(const AreaTab &t, int s) { return tab_w3(s, t.s1, t.s2, t.wh, t.wm, t.wt); }
 
-// per-level static tables, pass 1: hs of the level's picture right after a reset.  Grid (600 source rows, levels).
-__global__ __launch_bounds__(128) void npp_gv_static_h_kernel(KernelArgs a, float *gv_h) {
+// per-level static tables, pass 1: the level's picture right after a reset, pixel by pixel (gv_p, u8[600][1056]) and its
+// horizontal sums (gv_h).  Grid (600 source rows, levels).
+__global__ __launch_bounds__(256) void npp_gv_static_h_kernel(KernelArgs a, uint8_t *gv_p, float *gv_h) {
     __shared__ Draw s_draw[GV_DRAW];
     __shared__ int s_n;
-    __shared__ int s_wc[2];
+    __shared__ int s_wc[4];
+    __shared__ unsigned char s_row[1056];
     const int y = blockIdx.x, lvl = blockIdx.y;
     const LevelHdr &H = a.hdr[lvl];
     DrawCtx c{&a, &H, 0, -16.f, y - 16.f, 1056.f + 16.f, y + 1 + 16.f, true};
@@ -732,17 +723,20 @@ __global__ __launch_bounds__(128) void npp_gv_static_h_kernel(KernelArgs a, floa
         const bool keep = k < n_draw && entity_drawable(c, k, d);
         append_ordered(keep, d, s_draw, GV_DRAW, &s_n, s_wc);
     }
+    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
+    uint8_t *prow = gv_p + ((size_t)lvl * 600 + y) * 1056;
+    for (int x = threadIdx.x; x < 1056; x += blockDim.x) {
+        const unsigned char v = (unsigned char)canvas_pixel(s_draw, s_n, canvas, x, y);
+        s_row[x] = v;
+        prow[x] = v;
+    }
+    __syncthreads();
     const int col = threadIdx.x;
     if (col >= GV_COLS) return;
     const AreaTab tx = gv_col_tab(col);
-    int near[24], nn = 0;
-    for (int k = 0; k < s_n; k++) {
-        float cx, cy, ex, ey;
-        draw_extent(s_draw[k], cx, cy, ex, ey);
-        if (cx + ex >= tx.a && cx - ex <= tx.b && cy + ey >= y && cy - ey <= y + 1 && nn < 24) near[nn++] = k;
-    }
-    const uint8_t *crow = a.tile_canvas + ((size_t)lvl * 600 + y) * 1056;
-    gv_h[((size_t)lvl * 600 + y) * GV_COLS + col] = gv_hsum(s_draw, near, nn, crow, y, tx);
+    float hs = 0.f;
+    for (int x = tx.a; x < tx.b; x++) hs += tab_w3(x, tx.s1, tx.s2, tx.wh, tx.wm, tx.wt) * (float)s_row[x];
+    gv_h[((size_t)lvl * 600 + y) * GV_COLS + col] = hs;
 }
 
 // pass 2: the level's view from its hs table.  Grid (176 destination rows, levels).
@@ -755,138 +749,475 @@ __global__ __launch_bounds__(128) void npp_gv_static_v_kernel(const float *gv_h,
     gv_v[((size_t)lvl * GV_ROWS + r) * GV_COLS + col] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
 }
 
+constexpr int GV_Q = 512, GV_WORDS = (GV_CELLS + 31) / 32;
+constexpr int GV_PBOX = 32, GV_PATCH = 3072;   // dirty boxes whose pixels are composed up front into LDS patches, patch bytes
+// LDS of one env (dynamic: the draw list and the box list are sized for the level SET -- the largest number of draw records of
+// a loaded level -- so that ordinary sets leave room for 12 wavefronts per CU instead of 8)
 struct GvLds {
-    Draw draw[GV_DRAW];
-    float4 box[2 * GV_DRAW + 2];            // dirty boxes: x0, y0, x1, y1 (canvas pixels, conservative)
-    uint32_t dirty[(GV_CELLS + 31) / 32];   // destination cells to recompute
-    unsigned short queue[GV_CELLS];
-    int nd, nb, nq;
-    int wc[4];
+    Draw *draw;                   // [draw_cap]
+    uchar4 *cbox;                 // [draw_cap] destination cells a drawable can touch: row0, row1, col0, col1 (inclusive, conservative)
+    short4 *box;                  // [box_cap] dirty boxes: the canvas pixels x0..x1, y0..y1 (inclusive) a changed drawable can cover
+    uint32_t *dirty;              // [GV_WORDS] destination cells to recompute
+    unsigned short *queue;        // [GV_Q]
+    short4 *prect;                // [GV_PBOX] pixel rectangle of a patched box: x0, y0, width, height; width 0 = no patch
+    unsigned short *poff;         // [GV_PBOX] its first byte in patch[]
+    unsigned char *patch;         // [GV_PATCH]
+    int *ctr;                     // [0] boxes pushed, [1] cells queued, [2] cells left for another round
+    int draw_cap, box_cap;
 };
+__host__ __device__ inline int gv_box_cap(int draw_cap) { return 2 * draw_cap + 2 < 192 ? 2 * draw_cap + 2 : 192; }
+__host__ __device__ inline size_t gv_lds_bytes(int draw_cap) {
+    const int dc4 = (draw_cap + 3) & ~3;
+    return (size_t)dc4 * sizeof(Draw) + (size_t)dc4 * 4 + (size_t)gv_box_cap(draw_cap) * 8 + GV_WORDS * 4 + GV_Q * 2 + GV_PBOX * 8 + GV_PBOX * 2 +
+           GV_PATCH + 16;
+}
+__device__ inline GvLds gv_lds_layout(unsigned char *base, int draw_cap) {
+    GvLds L;
+    const int dc4 = (draw_cap + 3) & ~3;   // sizeof(Draw) = 28: four of them keep 16-byte alignment
+    L.draw_cap = draw_cap; L.box_cap = gv_box_cap(draw_cap);
+    L.draw = reinterpret_cast<Draw *>(base); base += (size_t)dc4 * sizeof(Draw);
+    L.cbox = reinterpret_cast<uchar4 *>(base); base += (size_t)dc4 * 4;
+    L.box = reinterpret_cast<short4 *>(base); base += (size_t)L.box_cap * 8;
+    L.dirty = reinterpret_cast<uint32_t *>(base); base += GV_WORDS * 4;
+    L.prect = reinterpret_cast<short4 *>(base); base += GV_PBOX * 8;
+    L.ctr = reinterpret_cast<int *>(base); base += 16;
+    L.queue = reinterpret_cast<unsigned short *>(base); base += GV_Q * 2;
+    L.poff = reinterpret_cast<unsigned short *>(base); base += GV_PBOX * 2;
+    L.patch = base;
+    return L;
+}
 
 __device__ inline bool draw_differs(const Draw &p, const Draw &q) {
     return p.x != q.x || p.y != q.y || p.r != q.r || p.x2 != q.x2 || p.y2 != q.y2 || p.gray != q.gray || p.shape != q.shape;
 }
-__device__ inline void gv_push_box(GvLds &L, const Draw &d) {
+// The canvas pixels a drawable can cover: pixel p spans [p, p + 1), every coverage sample lies inside its pixel, and a sample is
+// covered only within r of the disc centre / square centre / stroke axis -- so pixels floor(c - e) .. floor(c + e) with e the
+// half extent WITHOUT the anti-aliasing margin draw_extent() adds for culling.
+__device__ inline void gv_push_box(const GvLds &L, const Draw &d) {
     float cx, cy, ex, ey;
     draw_extent(d, cx, cy, ex, ey);
-    const int i = atomicAdd(&L.nb, 1);
-    if (i < 2 * GV_DRAW + 2) L.box[i] = make_float4(cx - ex, cy - ey, cx + ex, cy + ey);
+    ex -= 1.f; ey -= 1.f;
+    int x0 = (int)floorf(cx - ex), x1 = (int)floorf(cx + ex), y0 = (int)floorf(cy - ey), y1 = (int)floorf(cy + ey);
+    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > 1055 ? 1055 : x1; y1 = y1 > 599 ? 599 : y1;
+    if (x1 < x0 || y1 < y0) return;   // nothing of it on the canvas
+    const int i = atomicAdd(&L.ctr[0], 1);
+    if (i < L.box_cap) L.box[i] = make_short4((short)x0, (short)y0, (short)x1, (short)y1);
+}
+// destination rows / columns whose source range can meet [lo, hi] (one cell of slack on each side)
+__device__ inline void gv_cell_range(float lo, float hi, float scale, int n, int &i0, int &i1) {
+    i0 = (int)floorf(lo / scale) - 1; i1 = (int)floorf(hi / scale) + 1;
+    i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);
+    i1 = i1 < 0 ? 0 : (i1 > n - 1 ? n - 1 : i1);
+}
+__device__ inline uchar4 gv_cell_box(const Draw &d) {
+    float cx, cy, ex, ey;
+    draw_extent(d, cx, cy, ex, ey);
+    int r0, r1, c0, c1;
+    gv_cell_range(cy - ey, cy + ey, 600.f / GV_ROWS, GV_ROWS, r0, r1);
+    gv_cell_range(cx - ex, cx + ex, 1056.f / GV_COLS, GV_COLS, c0, c1);
+    return make_uchar4((unsigned char)r0, (unsigned char)r1, (unsigned char)c0, (unsigned char)c1);
+}
+__device__ inline void wave_sync() {   // LDS traffic of one wavefront: order it, no s_barrier needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void npp_global_view_kernel(KernelArgs a, const float *gv_h, const uint8_t *gv_v, uint8_t *out) {
-    __shared__ GvLds L;
-    const int env = blockIdx.x;
+// One WAVEFRONT per env (the per-env work is small and serial phases dominate: no workgroup barriers, ~20 KB of LDS, many envs
+// in flight per CU).  Phases: copy the level's view; build the current draw list from the level's compact draw-order records
+// and collect the dirty boxes; mark + queue the dirty destination cells; recompute them, 8 lanes per cell (one source row per
+// lane, then an ordered accumulation through lane 0 of the group).
+__global__ __launch_bounds__(64) void npp_global_view_kernel(KernelArgs a, int draw_cap, const uint8_t *gv_p, const float *gv_h,
+                                                              const uint8_t *gv_v, uint8_t *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gv_lds[];
+    const GvLds L = gv_lds_layout(gv_lds, draw_cap);
+    const int env = blockIdx.x, lane = threadIdx.x;
     if (env >= a.n) return;
+#ifdef NPP_GV_STATS
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    int stat_nq = 0;
+    uint32_t stat_a = 0, stat_b = 0, stat_c = 0, stat_d = 0, stat_e = 0, stat_it = 0;
+#endif
     const int lvl = __builtin_amdgcn_readfirstlane(a.env_level[env]);
     const LevelHdr &H = a.hdr[lvl];
     const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
-    for (int i = threadIdx.x; i < (GV_CELLS + 31) / 32; i += blockDim.x) L.dirty[i] = 0u;
-    if (threadIdx.x == 0) { L.nd = 0; L.nb = 0; L.nq = 0; }
-    // the level's view, to be patched below (dword copy: 17 600 B)
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(gv_v + (size_t)lvl * GV_CELLS);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
-        for (int i = threadIdx.x; i < GV_CELLS / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = lane; i < GV_WORDS; i += 64) L.dirty[i] = 0u;
+    if (lane == 0) { L.ctr[0] = 0; L.ctr[1] = 0; L.ctr[2] = 0; }
+    {   // the level's view, to be patched below
+        const uint8_t *src = gv_v + (size_t)lvl * GV_CELLS;
+        uint8_t *dst = out + (size_t)env * GV_CELLS;
+        if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+            static_assert(GV_CELLS / 16 == 17 * 64 + 12, "view copied as 17 full wavefront rows of uint4 + 12");
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src) + lane;
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst) + lane;
+#define GV_COPY6(o)                                                                                                        \
+    {                                                                                                                      \
+        const uint4 v0 = s4[(o) * 64], v1 = s4[(o + 1) * 64], v2 = s4[(o + 2) * 64], v3 = s4[(o + 3) * 64],               \
+                    v4 = s4[(o + 4) * 64], v5 = s4[(o + 5) * 64];                                                          \
+        d4[(o) * 64] = v0; d4[(o + 1) * 64] = v1; d4[(o + 2) * 64] = v2; d4[(o + 3) * 64] = v3;                            \
+        d4[(o + 4) * 64] = v4; d4[(o + 5) * 64] = v5;                                                                      \
     }
-    __syncthreads();
+            GV_COPY6(0) GV_COPY6(6)   // six loads in flight per lane
+            {
+                const uint4 v0 = s4[12 * 64], v1 = s4[13 * 64], v2 = s4[14 * 64], v3 = s4[15 * 64], v4 = s4[16 * 64];
+                uint4 v5 = v0;
+                if (lane < 12) v5 = s4[17 * 64];
+                d4[12 * 64] = v0; d4[13 * 64] = v1; d4[14 * 64] = v2; d4[15 * 64] = v3; d4[16 * 64] = v4;
+                if (lane < 12) d4[17 * 64] = v5;
+            }
+#undef GV_COPY6
+        } else {
+            for (int i = lane; i < GV_CELLS; i += 64) dst[i] = src[i];
+        }
+    }
+    wave_sync();
+#ifdef NPP_GV_STATS
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- current draw list (draw order) + dirty boxes
-    DrawCtx cc{&a, &H, env, -16.f, -16.f, 1056.f + 16.f, 600.f + 16.f, false};
-    DrawCtx ci = cc;
-    ci.init = true;
-    const uint32_t n_draw = H.n_ent + H.n_mov;
-    for (uint32_t d0 = 0; d0 < H.n_door; d0 += blockDim.x) {
-        Draw d = {}, di = {};
-        const uint32_t k = d0 + threadIdx.x;
-        const bool kc = k < H.n_door && door_drawable(cc, k, d);
-        const bool ki = k < H.n_door && door_drawable(ci, k, di);
-        if (kc != ki || (kc && draw_differs(d, di))) {
-            if (kc) gv_push_box(L, d);
-            if (ki) gv_push_box(L, di);
+    const float wx0 = -16.f, wy0 = -16.f, wx1 = 1056.f + 16.f, wy1 = 600.f + 16.f;
+    int nd = 0;
+    auto append = [&](bool keep, const Draw &d) {
+        const unsigned long long bal = __ballot(keep);
+        const int pos = nd + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && pos < L.draw_cap) { L.draw[pos] = d; L.cbox[pos] = gv_cell_box(d); }
+        nd += __popcll(bal);
+    };
+    if (H.n_door) {
+        DrawCtx cc{&a, &H, env, wx0, wy0, wx1, wy1, false};
+        DrawCtx ci = cc;
+        ci.init = true;
+        for (uint32_t d0 = 0; d0 < H.n_door; d0 += 64) {
+            Draw d = {}, di = {};
+            const uint32_t k = d0 + lane;
+            const bool kc = k < H.n_door && door_drawable(cc, k, d);
+            const bool ki = k < H.n_door && door_drawable(ci, k, di);
+            if (kc != ki || (kc && draw_differs(d, di))) {
+                if (kc) gv_push_box(L, d);
+                if (ki) gv_push_box(L, di);
+            }
+            append(kc, d);
         }
-        append_ordered(kc, d, L.draw, GV_DRAW, &L.nd, L.wc);
     }
-    for (uint32_t k0 = 0; k0 < n_draw; k0 += blockDim.x) {
-        Draw d = {}, di = {};
-        const uint32_t k = k0 + threadIdx.x;
-        const bool kc = k < n_draw && entity_drawable(cc, k, d);
-        const bool ki = k < n_draw && entity_drawable(ci, k, di);
-        if (kc != ki || (kc && draw_differs(d, di))) {
-            if (kc) gv_push_box(L, d);
-            if (ki) gv_push_box(L, di);
+    {
+        const uint4 *recs = reinterpret_cast<const uint4 *>(a.blob + H.off_draw_recs);
+        const uint32_t *init_words = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
+        const uint32_t n_draw = H.n_ent + H.n_mov;
+        const double *zhead = a.zoo ? a.zoo + (size_t)env * a.zoo_words : nullptr;
+        const uint32_t ovr = zhead ? reinterpret_cast<const uint32_t *>(zhead + 3)[0] : 0u;   // npp_set_entity_pos
+        for (uint32_t k0 = 0; k0 < n_draw; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            bool kc = false, ki = false;
+            Draw d = {}, di = {};
+            if (k < n_draw) {
+                const uint4 rc = recs[k];
+                const float x0 = __uint_as_float(rc.x), y0 = __uint_as_float(rc.y);
+                float x = x0, y = y0;
+                const uint32_t info = rc.z;
+                const int slot = (int)(info >> 16);
+                const bool mover = (info & 0x8000u) != 0;
+                bool live = true;
+                if (mover) {   // position from the env's zoo block
+                    live = zhead != nullptr && H.has_zoo;
+                    if (live) {
+                        const double *zb = zhead + ZOO_HEAD + (a.zoo_doors + 1) / 2 + ZOO_MOV_WORDS * slot;
+                        x = (float)zb[0]; y = (float)zb[1];
+                    }
+                } else if (ovr) {
+                    if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)zhead[4]; y = (float)zhead[5]; }
+                    if (slot == H.obs_door && (ovr & ZOO_OVR_DOOR)) { x = (float)zhead[6]; y = (float)zhead[7]; }
+                }
+                if (live && !(x < wx0 || x > wx1 || y < wy0 || y > wy1))
+                    kc = rec_drawable(info, x, y, mover ? 1u : ent_state_of(a, env, slot), d);
+                if (!mover && !(x0 < wx0 || x0 > wx1 || y0 < wy0 || y0 > wy1))
+                    ki = rec_drawable(info, x0, y0, (init_words[slot >> 4] >> ((slot & 15) * 2)) & 3u, di);
+                if (kc != ki || (kc && draw_differs(d, di))) {
+                    if (kc) gv_push_box(L, d);
+                    if (ki) gv_push_box(L, di);
+                }
+            }
+            append(kc, d);
         }
-        append_ordered(kc, d, L.draw, GV_DRAW, &L.nd, L.wc);
     }
-    if (threadIdx.x == 0) {   // the ninja, drawn last
+    nd = nd < L.draw_cap - 1 ? nd : L.draw_cap - 1;
+    if (lane == 0) {   // the ninja, drawn last
         const Draw nj = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};
-        if (L.nd < GV_DRAW) L.draw[L.nd++] = nj;
+        L.draw[nd] = nj;
+        L.cbox[nd] = gv_cell_box(nj);
         gv_push_box(L, nj);
     }
-    __syncthreads();
-    const int nd = L.nd, nb = L.nb < 2 * GV_DRAW + 2 ? L.nb : 2 * GV_DRAW + 2;
+    nd += 1;
+    for (int k = nd + lane; k < ((nd + 3) & ~3); k += 64) L.cbox[k] = make_uchar4(255, 0, 255, 0);   // pad the last group of four: empty
+    wave_sync();
+    if (L.ctr[0] > L.box_cap) {   // more dirty boxes than the list holds (a crowd of movers): everything is dirty, composed in the
+        wave_sync();              // cell pass -- slow and exact
+        if (lane == 0) { L.ctr[0] = 1; L.box[0] = make_short4(0, 0, 1055, 599); }
+        wave_sync();
+    }
+    const int nb = L.ctr[0];
+    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
+    // ---- the pixels inside the dirty boxes, composed ONE PER LANE into LDS patches (full wavefronts run the coverage sampler;
+    //      the cell pass below then only sums bytes).  Boxes beyond the patch budget (many movers) are composed in the cell pass.
+    const int npb = nb < GV_PBOX ? nb : GV_PBOX;
+    if (lane == 0) {
+        int used = 0;
+        for (int b = 0; b < npb; b++) {
+            const short4 bx = L.box[b];
+            const int w = bx.z - bx.x + 1, h = bx.w - bx.y + 1;
+            if (used + w * h <= GV_PATCH) {
+                L.prect[b] = make_short4(bx.x, bx.y, (short)w, (short)h);
+                L.poff[b] = (unsigned short)used;
+                used += w * h;
+            } else {
+                L.prect[b] = make_short4(0, 0, 0, 0);   // width 0: no patch, composed in the cell pass
+                L.poff[b] = 0;
+            }
+        }
+    }
+    wave_sync();
+    for (int b = 0; b < npb; b++) {
+        const short4 pr = L.prect[b];
+        if (pr.z == 0) continue;
+        // drawables that can touch the rectangle: the same set for every lane (scalar masks)
+        unsigned long long bm[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            bool hit = false;
+            const int k = w * 64 + lane;
+            if (k < nd) {
+                float cx, cy, ex, ey;
+                draw_extent(L.draw[k], cx, cy, ex, ey);
+                hit = cx + ex >= pr.x && cx - ex <= pr.x + pr.z && cy + ey >= pr.y && cy - ey <= pr.y + pr.w;
+            }
+            bm[w] = __ballot(hit);
+        }
+        const int np = pr.z * pr.w, pbase = L.poff[b];
+        for (int i0 = lane; i0 < np; i0 += 128) {   // two pixels per lane and trip: their canvas loads overlap
+            int xs[2], ys[2], cn[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + 64 * u < np ? i0 + 64 * u : i0;
+                const int yy = i / pr.z;
+                xs[u] = pr.x + (i - yy * pr.z); ys[u] = pr.y + yy;
+                cn[u] = canvas[(size_t)ys[u] * 1056 + xs[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                float eg = 0.f, ea = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    unsigned long long m = bm[w];
+                    while (m) {
+                        const Draw &d = L.draw[w * 64 + __builtin_ctzll(m)];
+                        m &= m - 1;
+                        const int cnt = draw_cover(d, xs[u], ys[u]);
+                        if (cnt) {
+                            float cov = cnt * (1.f / 16.f);
+                            eg = eg * (1.f - cov) + d.gray * cov;
+                            ea = ea * (1.f - cov) + cov;
+                        }
+                    }
+                }
+                if (i0 + 64 * u < np) L.patch[pbase + i0 + 64 * u] = (unsigned char)composite(eg, ea, cn[u]);
+            }
+        }
+    }
+#ifdef NPP_GV_STATS
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- destination cells under the dirty boxes
     const float sx = 1056.f / GV_COLS, sy = 600.f / GV_ROWS;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-        const float4 bx = L.box[b];
+    for (int b = 0; b < nb; b++) {   // the lanes share one box's candidate cells (a box covers a few rows x a few columns)
+        const short4 bx = L.box[b];
         int c0 = (int)floorf(bx.x / sx) - 1, c1 = (int)floorf(bx.z / sx) + 1, r0 = (int)floorf(bx.y / sy) - 1, r1 = (int)floorf(bx.w / sy) + 1;
         c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
         c1 = c1 > GV_COLS - 1 ? GV_COLS - 1 : c1; r1 = r1 > GV_ROWS - 1 ? GV_ROWS - 1 : r1;
-        for (int r = r0; r <= r1; r++) {
-            const AreaTab ty = gv_row_tab(r);
-            if (!(bx.w >= ty.a && bx.y <= ty.b)) continue;
-            for (int c = c0; c <= c1; c++) {
-                const AreaTab tx = gv_col_tab(c);
-                if (!(bx.z >= tx.a && bx.x <= tx.b)) continue;
+        const int nc = c1 - c0 + 1, cells = nc * (r1 - r0 + 1);
+        for (int i = lane; i < cells; i += 64) {
+            const int r = r0 + i / nc, c = c0 + i % nc;
+            const AreaTab ty = gv_row_tab(r), tx = gv_col_tab(c);
+            if (bx.w >= ty.a && bx.y < ty.b && bx.z >= tx.a && bx.x < tx.b) {   // source pixels [a, b) meet the box
                 const int cell = r * GV_COLS + c;
                 atomicOr(&L.dirty[cell >> 5], 1u << (cell & 31));
             }
         }
     }
-    __syncthreads();
-    for (int w = threadIdx.x; w < (GV_CELLS + 31) / 32; w += blockDim.x) {
-        uint32_t m = L.dirty[w];
-        while (m) {
-            const int bit = __builtin_ctz(m);
-            m &= m - 1;
-            L.queue[atomicAdd(&L.nq, 1)] = (unsigned short)(w * 32 + bit);
-        }
-    }
-    __syncthreads();
-    // ---- recompute the dirty cells, one per lane
-    const int nq = L.nq;
-    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
+    wave_sync();
+    const uint8_t *pstat = gv_p + (size_t)lvl * 600 * 1056;
     const float *hrow = gv_h + (size_t)lvl * 600 * GV_COLS;
-    for (int qi = threadIdx.x; qi < nq; qi += blockDim.x) {
-        const int cell = L.queue[qi], r = cell / GV_COLS, c = cell - r * GV_COLS;
-        const AreaTab tx = gv_col_tab(c), ty = gv_row_tab(r);
-        int near[24], nn = 0;
-        for (int k = 0; k < nd; k++) {
-            float cx, cy, ex, ey;
-            draw_extent(L.draw[k], cx, cy, ex, ey);
-            if (cx + ex >= tx.a && cx - ex <= tx.b && cy + ey >= ty.a && cy - ey <= ty.b && nn < 24) near[nn++] = k;
-        }
-        unsigned short nbox[16];
-        int nbx = 0;
-        bool all_rows = false;   // more boxes than the list holds: recompute every row of the cell
-        for (int b = 0; b < nb; b++) {
-            const float4 bx = L.box[b];
-            if (bx.z >= tx.a && bx.x <= tx.b && bx.w >= ty.a && bx.y <= ty.b) {
-                if (nbx < 16) nbox[nbx++] = (unsigned short)b;
-                else all_rows = true;
+    const int grp = lane >> 3, sub = lane & 7;
+#ifdef NPP_GV_STATS
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+    // the dword copy of the view must have landed before single bytes of it are overwritten
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    for (;;) {
+        // queue (up to GV_Q of) the dirty cells; a cell that does not fit keeps its bit for the next round
+        for (int w = lane; w < GV_WORDS; w += 64) {
+            uint32_t m = L.dirty[w], left = 0u;
+            while (m) {
+                const int bit = __builtin_ctz(m);
+                m &= m - 1;
+                const int slot = atomicAdd(&L.ctr[1], 1);
+                if (slot < GV_Q) L.queue[slot] = (unsigned short)(w * 32 + bit);
+                else { left |= 1u << bit; L.ctr[2] = 1; }
             }
+            L.dirty[w] = left;
         }
-        float acc = 0.f;
-        for (int y = ty.a; y < ty.b; y++) {
-            bool touched = all_rows;
-            for (int q = 0; q < nbx && !touched; q++) {
-                const float4 bx = L.box[nbox[q]];
-                touched = bx.w >= y && bx.y <= y + 1;
+        wave_sync();
+        const int nq = L.ctr[1] < GV_Q ? L.ctr[1] : GV_Q;
+        const int more = L.ctr[2];
+#ifdef NPP_GV_STATS
+        stat_nq += nq;
+#endif
+        for (int qi = grp; qi < nq; qi += 8) {
+#ifdef NPP_GV_STATS
+            const unsigned long long u0 = __builtin_amdgcn_s_memtime();
+#endif
+            const int cell = L.queue[qi], r = cell / GV_COLS, c = cell - r * GV_COLS;
+            const AreaTab tx = gv_col_tab(c), ty = gv_row_tab(r);
+            const int tx_s1 = tx.s1, tx_s2 = tx.s2, ty_s1 = ty.s1, ty_s2 = ty.s2;
+            const float tx_wh = tx.wh, tx_wm = tx.wm, tx_wt = tx.wt, ty_wh = ty.wh, ty_wm = ty.wm, ty_wt = ty.wt;
+            const int y = ty.a + sub;   // this lane's source row (a destination row spans at most 6)
+            // issued before the mask work so that their latency is hidden: the row's static hs and its static picture slice
+            // (at most 12 pixels -> four aligned dwords; the table is padded by 16 bytes)
+            const int xb0 = tx.a & ~3;
+            const int yl = y < 599 ? y : 599;
+            const float hs_static = hrow[(size_t)yl * GV_COLS + c];
+            const uint32_t *pp = reinterpret_cast<const uint32_t *>(pstat + (size_t)yl * 1056 + xb0);   // dword aligned
+            const uint4 pw = make_uint4(pp[0], pp[1], pp[2], pp[3]);
+            // the drawables that can touch this cell: the group's lanes share the scan of the cell boxes (four per 16-byte
+            // LDS read), then OR their masks together
+            unsigned long long nm[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                unsigned long long m = 0ull;
+                if (w * 64 >= nd) { nm[w] = 0ull; continue; }   // wavefront-uniform
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int chunk = w * 16 + h * 8 + sub;   // drawables 4 chunk .. 4 chunk + 3
+                    if (chunk * 4 < nd) {
+                        const uint4 cb = reinterpret_cast<const uint4 *>(L.cbox)[chunk];
+                        const uint32_t q[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int br0 = q[j] & 255u, br1 = (q[j] >> 8) & 255u, bc0 = (q[j] >> 16) & 255u, bc1 = q[j] >> 24;
+                            if (r >= br0 && r <= br1 && c >= bc0 && c <= bc1) m |= 1ull << ((h * 8 + sub) * 4 + j);
+                        }
+                    }
+                }
+                uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+#pragma unroll
+                for (int sft = 1; sft < 8; sft <<= 1) {
+                    lo |= (uint32_t)__shfl_xor((int)lo, sft, 64);
+                    hi |= (uint32_t)__shfl_xor((int)hi, sft, 64);
+                }
+                nm[w] = ((unsigned long long)hi << 32) | lo;
             }
-            const float hs = touched ? gv_hsum(L.draw, near, nn, canvas + (size_t)y * 1056, y, tx) : hrow[(size_t)y * GV_COLS + c];
-            acc += tab_w(ty, y) * hs;
+#ifdef NPP_GV_STATS
+            const unsigned long long u1 = __builtin_amdgcn_s_memtime();
+#endif
+            float hs = 0.f;
+            if (y < ty.b) {
+                // the part of this row slice inside dirty boxes: only those pixels are composed again, the others come from
+                // the level's static picture (a pixel outside every dirty box is covered by the same drawables as after the
+                // reset, in the same order)
+                int hx0 = 4096, hx1 = -4096;
+                int pa = -1, pb = -1;      // patched boxes on this row slice (two are remembered)
+                bool inline_compose = false;
+                for (int b = 0; b < nb; b++) {
+                    const short4 bx = L.box[b];
+                    if (bx.z >= tx.a && bx.x < tx.b && bx.w >= y && bx.y <= y) {
+                        hx0 = hx0 < bx.x ? hx0 : bx.x; hx1 = hx1 > bx.z ? hx1 : bx.z;
+                        if (b < GV_PBOX && L.prect[b].z > 0) {
+                            if (pa < 0) pa = b;
+                            else if (pb < 0) pb = b;
+                            else inline_compose = true;
+                        } else {
+                            inline_compose = true;
+                        }
+                    }
+                }
+#ifdef NPP_GV_STATS
+                stat_d += (uint32_t)(__builtin_amdgcn_s_memtime() - u1);
+#endif
+                if (hx1 < hx0) {
+                    hs = hs_static;
+                } else {
+                    short4 ra = make_short4(0, 0, 0, 0), rb = ra;
+                    int oa = 0, ob = 0;
+                    if (pa >= 0) { ra = L.prect[pa]; oa = L.poff[pa] + (y - ra.y) * ra.z - ra.x; if (y < ra.y || y >= ra.y + ra.w) ra.z = 0; }
+                    if (pb >= 0) { rb = L.prect[pb]; ob = L.poff[pb] + (y - rb.y) * rb.z - rb.x; if (y < rb.y || y >= rb.y + rb.w) rb.z = 0; }
+                    if (!inline_compose) {
+                        for (int x = tx.a; x < tx.b; x++) {
+                            const int o = x - xb0, sh = (o & 3) * 8;
+                            int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
+                            if (x >= ra.x && x < ra.x + ra.z) pix = L.patch[oa + x];
+                            else if (x >= rb.x && x < rb.x + rb.z) pix = L.patch[ob + x];
+                            hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pix;
+                        }
+                    } else {
+                        const uint32_t *cp = reinterpret_cast<const uint32_t *>(canvas + (size_t)y * 1056 + xb0);
+                        const uint4 cw = make_uint4(cp[0], cp[1], cp[2], cp[3]);
+                        for (int x = tx.a; x < tx.b; x++) {
+                            const int o = x - xb0, sh = (o & 3) * 8;
+                            int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
+                            if (x >= hx0 && x <= hx1) {
+                                float eg = 0.f, ea = 0.f;
+#pragma unroll
+                                for (int w = 0; w < 4; w++) {
+                                    unsigned long long m = nm[w];
+                                    while (m) {
+                                        const Draw &d = L.draw[w * 64 + __builtin_ctzll(m)];
+                                        m &= m - 1;
+                                        const int cnt = draw_cover(d, x, y);
+                                        if (cnt) {
+                                            float cov = cnt * (1.f / 16.f);
+                                            eg = eg * (1.f - cov) + d.gray * cov;
+                                            ea = ea * (1.f - cov) + cov;
+                                        }
+                                    }
+                                }
+                                pix = composite(eg, ea, (int)(((o < 4 ? cw.x : (o < 8 ? cw.y : (o < 12 ? cw.z : cw.w))) >> sh) & 0xffu));
+                            }
+                            hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pix;
+                        }
+                    }
+                }
+            }
+#ifdef NPP_GV_STATS
+            const unsigned long long u2 = __builtin_amdgcn_s_memtime();
+#endif
+            // ordered vertical accumulation (y ascending) through the group's lanes
+            float acc = 0.f;
+            const int rows = ty.b - ty.a;
+#pragma unroll
+            for (int jr = 0; jr < 8; jr++) {
+                const float h = __shfl(hs, (lane & ~7) + jr, 64);
+                if (jr < rows) acc += tab_w3(ty.a + jr, ty_s1, ty_s2, ty_wh, ty_wm, ty_wt) * h;
+            }
+            if (sub == 0) out[(size_t)env * GV_CELLS + cell] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
+#ifdef NPP_GV_STATS
+            const unsigned long long u3 = __builtin_amdgcn_s_memtime();
+            stat_a += (uint32_t)(u1 - u0); stat_b += (uint32_t)(u2 - u1); stat_c += (uint32_t)(u3 - u2); stat_it += 1;
+#endif
         }
-        out[(size_t)env * GV_CELLS + cell] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
+        if (!more) break;
+        wave_sync();
+        if (lane == 0) { L.ctr[1] = 0; L.ctr[2] = 0; }
+        wave_sync();
     }
+#ifdef NPP_GV_STATS
+    wave_sync();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {   // diagnostic build only: phase durations (100 MHz ticks) and counts over the view's first bytes
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        uint32_t *dbg = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
+        dbg[0] = (uint32_t)(t1 - t0); dbg[1] = (uint32_t)(t2 - t1); dbg[2] = (uint32_t)(t3 - t2); dbg[3] = (uint32_t)(t4 - t3);
+        dbg[4] = (uint32_t)nd; dbg[5] = (uint32_t)nb; dbg[6] = (uint32_t)stat_nq; dbg[7] = H.n_ent + H.n_mov;
+        dbg[8] = stat_a; dbg[9] = stat_b; dbg[10] = stat_c; dbg[11] = stat_d; dbg[12] = stat_e; dbg[13] = stat_it;
+    }
+#endif
 }
 
 // The whole gray canvas of one env range (NPlayHeadless.render() in grayscale mode: nsim_renderer.py:71-134, array of shape
@@ -948,13 +1279,16 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_global_view(const KernelArgs &a, const float *gv_h, const uint8_t *gv_v, uint8_t *d_out, hipStream_t s) {
-    hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n), dim3(256), 0, s, a, gv_h, gv_v, d_out);
+hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_t *gv_p, const float *gv_h, const uint8_t *gv_v,
+                              uint8_t *d_out, hipStream_t s) {
+    int cap = max_records + 1;   // + the ninja
+    cap = cap < 16 ? 16 : (cap > GV_DRAW ? GV_DRAW : cap);
+    hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n), dim3(64), gv_lds_bytes(cap), s, a, cap, gv_p, gv_h, gv_v, d_out);
     return hipGetLastError();
 }
 
-hipError_t launch_gv_static(const KernelArgs &a, int n_levels, float *gv_h, uint8_t *gv_v, hipStream_t s) {
-    hipLaunchKernelGGL(npp_gv_static_h_kernel, dim3(600, n_levels), dim3(128), 0, s, a, gv_h);
+hipError_t launch_gv_static(const KernelArgs &a, int n_levels, uint8_t *gv_p, float *gv_h, uint8_t *gv_v, hipStream_t s) {
+    hipLaunchKernelGGL(npp_gv_static_h_kernel, dim3(600, n_levels), dim3(256), 0, s, a, gv_p, gv_h);
     hipLaunchKernelGGL(npp_gv_static_v_kernel, dim3(GV_ROWS, n_levels), dim3(128), 0, s, gv_h, gv_v);
     return hipGetLastError();
 }
