@@ -89,6 +89,7 @@ class NppAsyncVecEnvironment:
             level_ids = (np.arange(self.num_envs) // 64) % len(levels)
         self.ab.assign_levels(level_ids)
         self.ab.set_truncation_limit(truncation_limit)
+        self._reset_bits = 11 if autoreset else 0   # won | dead | truncated: the row holds the spawn observation
         self._acts = []
         for b in self.ab.batches:
             with b._ctx():
@@ -117,7 +118,9 @@ class NppAsyncVecEnvironment:
         flags, pos = src["flags"], src["positions"]
         obs = {"game_state": src["game_state"], "action_mask": src["action_mask"], "entity_positions": src["entity_pos"],
                "player_x": pos[:, 0], "player_y": pos[:, 1], "switch_x": pos[:, 2], "switch_y": pos[:, 3],
-               "exit_door_x": pos[:, 4], "exit_door_y": pos[:, 5], "switch_activated": (flags & 4) != 0}
+               "exit_door_x": pos[:, 4], "exit_door_y": pos[:, 5],
+               # as in NppVecEnvironment: an auto-reset row returns the spawn observation, whose switch is not yet hit
+               "switch_activated": ((flags & 4) != 0) & ((flags & self._reset_bits) == 0)}
         info = {"player_won": (flags & 1) != 0, "player_dead": (flags & 2) != 0, "death_cause_code": (flags >> 4) & 3,
                 "frames_executed": src["frames"], "terminal_observation": src["terminal_state"]}
         return obs, src["reward"], (flags & 3) != 0, (flags & 8) != 0, info
