@@ -25,7 +25,7 @@ for s in range(60):
 for _ in range(3):
     b.render_player_frame()
 torch.cuda.synchronize()
-fr = b.out.t["player_frame"].cpu().numpy().reshape(n, -1)[:, :32].copy().view(np.uint32)
+fr = b.out.t["player_frame"].cpu().numpy().reshape(n, -1)[:, :64].copy().view(np.uint32)
 f, _ = b.dump_state()
 live = f[:, 0] - 42 < 600
 st = fr[live].astype(np.float64)
@@ -35,4 +35,8 @@ for k, name in enumerate(["loads", "list build (wave 0)", "barrier", "shade+stor
 if st.shape[1] > 7:
     print("pass 1 (classify + plain spans) mean %.0f clocks; queued spans mean %.0f p95 %.0f max %d of 1764"
           % (st[:, 7].mean(), st[:, 6].mean(), np.percentile(st[:, 6], 95), st[:, 6].max()))
+if st.shape[1] > 12:
+    for k, name in zip(range(8, 13), ["build: header / pointers", "build: first record + state word", "build: drawables of round 0",
+                                      "build: appends + further rounds", "build: row masks"]):
+        print("%-36s mean %8.0f  p50 %8.0f clocks" % (name, st[:, k].mean(), np.median(st[:, k])))
 print("draw list length mean %.1f max %d; level entities mean %.0f" % (st[:, 4].mean(), st[:, 4].max(), st[:, 5].mean()))
