@@ -386,9 +386,17 @@ template <int STEP> DEV double partner_d(double v) {
     else return __shfl_xor(v, STEP, 64);
 }
 
+// v_min_f64 without the canonicalising v_max_f64 x, x, x that llvm.minnum puts in front of every operand it cannot prove
+// quiet (anything that went through a select or a DPP move): the operands here are never NaN (+inf / 1 mark "none"), and each
+// such instruction is ~7 cycles of the single wavefront's issue cadence inside the depenetration loop (five per iteration).
+DEV double min_nonan(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int G, int STEP = 1> DEV double group_min(double t) {
     if constexpr (STEP < G) {
-        t = __builtin_fmin(t, partner_d<STEP>(t));   // operands are never NaN (+inf / 1 mark "none")
+        t = min_nonan(t, partner_d<STEP>(t));
         return group_min<G, STEP * 2>(t);
     } else {
         return t;
