@@ -1321,7 +1321,7 @@ DEV uint32_t action_mask_bits(const Nj &n) {
 //   [64, 112) compute_mine_overlay_from_entities (:309-367 -> :370-508): 8 nearest mines (entity_dic[1] then
 //             entity_dic[21], stable sort by distance) x (dx/1056, dy/600, state code, radius code, velocity dot,
 //             distance rate), recomputed only when the ninja is >= 12 px from where it was last computed.
-// The lanes of a group split the copies; the nearest-8 selection runs redundantly on every lane.
+// The lanes of a group split the copies and the nearest-8 selection.
 template <int G>
 DEV void write_spatial_context(const KernelArgs &a, const LevelHdr &H, Nj &n, EntBits eb, int env, int r, bool valid) {
     if (!valid) return;
@@ -1349,42 +1349,66 @@ DEV void write_spatial_context(const KernelArgs &a, const LevelHdr &H, Nj &n, En
         for (int k = r; k < 48; k += G) out[64 + k] = cache[k];
         return;
     }
+    // Nearest eight, lanes of the group in parallel (round 2; the redundant serial scan of up to 130 mines with three dependent
+    // loads, an fp64 square root and an 8-deep insertion each was ~50 us of a 336 us step on the door levels): lane r scans
+    // draw-order entries r, r + G, ... into its own stable top-8 (distance, then entry index: `tag` = index << 15 | slot), then
+    // eight rounds of "smallest (distance, tag) among the lanes' heads" merge them -- the same total order as one serial scan.
     double bd[8];
-    int bs[8];
+    int bt[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { bd[k] = __builtin_inf(); bs[k] = -1; }
+    for (int k = 0; k < 8; k++) { bd[k] = __builtin_inf(); bt[k] = 0x7fffffff; }
     const uint16_t *order = reinterpret_cast<const uint16_t *>(a.blob + H.off_raster);
     const double *ex = reinterpret_cast<const double *>(a.blob + H.off_ent_x);
     const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);
     const uint32_t *meta = reinterpret_cast<const uint32_t *>(a.blob + H.off_ent_meta);
-    for (uint32_t i = 0; i < H.n_ent + H.n_mov; i++) {
+    for (uint32_t i = r; i < H.n_ent + H.n_mov; i += G) {
         int slot = order[i];   // draw order = type 1 mines in map order, ..., type 21 mines in map order
         if (slot & 0x8000) continue;   // a mover reference (npp_level.hpp: raster_order)
         if ((meta[slot] & 15u) != EK_MINE) continue;
         double dx = ex[slot] - n.x, dy = ey[slot] - n.y;
         double d = dsqrt(dx * dx + dy * dy);
         if (!(d < bd[7])) continue;
+        int tag = (int)((i << 15) | (uint32_t)slot);
         bool sw = false;
 #pragma unroll
         for (int k = 0; k < 8; k++) {   // stable insertion: an equal distance stays behind earlier entries, and
             sw = sw | (d < bd[k]);      // once placed, everything after it shifts down by one unconditionally
-            double td = bd[k]; int ts = bs[k];
-            bd[k] = sw ? d : td; bs[k] = sw ? slot : ts;
-            d = sw ? td : d; slot = sw ? ts : slot;
+            double td = bd[k]; int tt = bt[k];
+            bd[k] = sw ? d : td; bt[k] = sw ? tag : tt;
+            d = sw ? td : d; tag = sw ? tt : tag;
         }
     }
+    constexpr int OWN = G >= 8 ? 1 : 8 / G;   // results per lane: result k belongs to lane k % G
+    double od[OWN];
+    int os[OWN];
+#pragma unroll
+    for (int j = 0; j < OWN; j++) { od[j] = 0; os[j] = -1; }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
+        const double kmin = group_min<G>(bd[0]);
+        const int cand = (bd[0] == kmin) ? bt[0] : 0x7fffffff;   // empty heads carry tag 0x7fffffff at distance inf
+        const int tmin = group_min_i<G>(cand);
+        if (bt[0] == tmin && tmin != 0x7fffffff) {   // this lane's head won: pop it
+#pragma unroll
+            for (int q = 0; q < 7; q++) { bd[q] = bd[q + 1]; bt[q] = bt[q + 1]; }
+            bd[7] = __builtin_inf(); bt[7] = 0x7fffffff;
+        }
+        if (r == k % G) { od[k / G < OWN ? k / G : 0] = kmin; os[k / G < OWN ? k / G : 0] = tmin == 0x7fffffff ? -1 : (tmin & 0x7fff); }
+    }
+#pragma unroll
+    for (int j = 0; j < OWN; j++) {
+        const int k = j * G + r;
+        if (k >= 8) continue;
         float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (bs[k] >= 0) {
-            double dx = ex[bs[k]] - n.x, dy = ey[bs[k]] - n.y, dist = bd[k];
+        if (os[j] >= 0) {
+            double dx = ex[os[j]] - n.x, dy = ey[os[j]] - n.y, dist = od[j];
             double vd = 0.0, dr = 0.0;
             if (dist > 1e-6) {
                 double dirx = dx / dist, diry = dy / dist;
                 vd = (n.vx * dirx + n.vy * diry) / MAX_HOR_SPEED;
                 dr = -vd;
             }
-            uint32_t st = ent_get(eb, bs[k]);
+            uint32_t st = ent_get(eb, os[j]);
             f[0] = (float)clampd(dx / 1056.0, -1.0, 1.0);
             f[1] = (float)clampd(dy / 600.0, -1.0, 1.0);
             f[2] = st == 1 ? 1.0f : (st == 2 ? 0.0f : -1.0f);
@@ -1392,10 +1416,8 @@ DEV void write_spatial_context(const KernelArgs &a, const LevelHdr &H, Nj &n, En
             f[4] = (float)clampd(vd, -1.0, 1.0);
             f[5] = (float)clampd(dr, -1.0, 1.0);
         }
-        if (r == 0) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) { cache[6 * k + j] = f[j]; out[64 + 6 * k + j] = f[j]; }
-        }
+        for (int jj = 0; jj < 6; jj++) { cache[6 * k + jj] = f[jj]; out[64 + 6 * k + jj] = f[jj]; }
     }
     n.scvalid = 1; n.scx = n.x; n.scy = n.y;
 }

@@ -1210,45 +1210,50 @@ __global__ __launch_bounds__(64) void npp_global_view_kernel(KernelArgs a, int d
             const float hs_static = hrow[(size_t)yl * GV_COLS + c];
             const uint32_t *pp = reinterpret_cast<const uint32_t *>(pstat + (size_t)yl * 1056 + xb0);   // dword aligned
             const uint4 pw = make_uint4(pp[0], pp[1], pp[2], pp[3]);
-            // the drawables that can touch this cell: the group's lanes share the scan of the cell boxes (four per 16-byte
-            // LDS read), then OR their masks together
-            unsigned long long nm[4];
+            // the drawables that can touch this cell -- needed only by row slices that compose pixels in place (dirty boxes beyond
+            // the patch budget: a crowd of movers), so the scan runs only when some lane of the wavefront asks for it (it was
+            // 20 % of the cell pass when it ran for every cell): the group's lanes share the scan of the cell boxes (four per
+            // 16-byte LDS read), then OR their masks together
+            unsigned long long nm[4] = {0ull, 0ull, 0ull, 0ull};
+            auto scan_cell_masks = [&]() {
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                unsigned long long m = 0ull;
-                if (w * 64 >= nd) { nm[w] = 0ull; continue; }   // wavefront-uniform
+                for (int w = 0; w < 4; w++) {
+                    unsigned long long m = 0ull;
+                    if (w * 64 >= nd) { nm[w] = 0ull; continue; }   // wavefront-uniform
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int chunk = w * 16 + h * 8 + sub;   // drawables 4 chunk .. 4 chunk + 3
-                    if (chunk * 4 < nd) {
-                        const uint4 cb = reinterpret_cast<const uint4 *>(L.cbox)[chunk];
-                        const uint32_t q[4] = {cb.x, cb.y, cb.z, cb.w};
+                    for (int h = 0; h < 2; h++) {
+                        const int chunk = w * 16 + h * 8 + sub;   // drawables 4 chunk .. 4 chunk + 3
+                        if (chunk * 4 < nd) {
+                            const uint4 cb = reinterpret_cast<const uint4 *>(L.cbox)[chunk];
+                            const uint32_t q[4] = {cb.x, cb.y, cb.z, cb.w};
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int br0 = q[j] & 255u, br1 = (q[j] >> 8) & 255u, bc0 = (q[j] >> 16) & 255u, bc1 = q[j] >> 24;
-                            if (r >= br0 && r <= br1 && c >= bc0 && c <= bc1) m |= 1ull << ((h * 8 + sub) * 4 + j);
+                            for (int j = 0; j < 4; j++) {
+                                const int br0 = q[j] & 255u, br1 = (q[j] >> 8) & 255u, bc0 = (q[j] >> 16) & 255u, bc1 = q[j] >> 24;
+                                if (r >= br0 && r <= br1 && c >= bc0 && c <= bc1) m |= 1ull << ((h * 8 + sub) * 4 + j);
+                            }
                         }
                     }
-                }
-                uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+                    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
 #pragma unroll
-                for (int sft = 1; sft < 8; sft <<= 1) {
-                    lo |= (uint32_t)__shfl_xor((int)lo, sft, 64);
-                    hi |= (uint32_t)__shfl_xor((int)hi, sft, 64);
+                    for (int sft = 1; sft < 8; sft <<= 1) {
+                        lo |= (uint32_t)__shfl_xor((int)lo, sft, 64);
+                        hi |= (uint32_t)__shfl_xor((int)hi, sft, 64);
+                    }
+                    nm[w] = ((unsigned long long)hi << 32) | lo;
                 }
-                nm[w] = ((unsigned long long)hi << 32) | lo;
-            }
+            };
 #ifdef NPP_GV_STATS
             const unsigned long long u1 = __builtin_amdgcn_s_memtime();
 #endif
             float hs = 0.f;
-            if (y < ty.b) {
-                // the part of this row slice inside dirty boxes: only those pixels are composed again, the others come from
-                // the level's static picture (a pixel outside every dirty box is covered by the same drawables as after the
-                // reset, in the same order)
-                int hx0 = 4096, hx1 = -4096;
-                int pa = -1, pb = -1;      // patched boxes on this row slice (two are remembered)
-                bool inline_compose = false;
+            // the part of this row slice inside dirty boxes: only those pixels are composed again, the others come from the
+            // level's static picture (a pixel outside every dirty box is covered by the same drawables as after the reset, in
+            // the same order)
+            const bool row_live = y < ty.b;
+            int hx0 = 4096, hx1 = -4096;
+            int pa = -1, pb = -1;      // patched boxes on this row slice (two are remembered)
+            bool inline_compose = false;
+            if (row_live) {
                 for (int b = 0; b < nb; b++) {
                     const short4 bx = L.box[b];
                     if (bx.z >= tx.a && bx.x < tx.b && bx.w >= y && bx.y <= y) {
@@ -1262,9 +1267,12 @@ __global__ __launch_bounds__(64) void npp_global_view_kernel(KernelArgs a, int d
                         }
                     }
                 }
+            }
 #ifdef NPP_GV_STATS
-                stat_d += (uint32_t)(__builtin_amdgcn_s_memtime() - u1);
+            stat_d += (uint32_t)(__builtin_amdgcn_s_memtime() - u1);
 #endif
+            if (__any(inline_compose)) scan_cell_masks();   // whole wavefront: the scan shuffles across the group's lanes
+            if (row_live) {
                 if (hx1 < hx0) {
                     hs = hs_static;
                 } else {
