@@ -947,11 +947,17 @@ __device__ inline void wave_sync() {   // LDS traffic of one wavefront: order it
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Occupancy (round 2): 3 wavefronts per SIMD (136 VGPRs, ~12 KB of LDS per env on the door levels).  Capping the registers at
+// 128 and trimming the LDS for 4 per SIMD was measured and dropped (246 -> 288 us inside the config-5 step): the launch lasts as
+// long as its heaviest env (cells phase p50 36 k clocks, max 250-380 k), not as long as the average one.
+#ifndef NPP_GV_WAVES
+#define NPP_GV_WAVES 3
+#endif
 // One WAVEFRONT per env (the per-env work is small and serial phases dominate: no workgroup barriers, ~20 KB of LDS, many envs
 // in flight per CU).  Phases: copy the level's view; build the current draw list from the level's compact draw-order records
 // and collect the dirty boxes; mark + queue the dirty destination cells; recompute them, 8 lanes per cell (one source row per
 // lane, then an ordered accumulation through lane 0 of the group).
-__global__ __launch_bounds__(64) void npp_global_view_kernel(KernelArgs a, int draw_cap, const uint8_t *gv_p, const float *gv_h,
+__global__ __launch_bounds__(64, NPP_GV_WAVES) void npp_global_view_kernel(KernelArgs a, int draw_cap, const uint8_t *gv_p, const float *gv_h,
                                                               const uint8_t *gv_v, uint8_t *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gv_lds[];
     const GvLds L = gv_lds_layout(gv_lds, draw_cap);

@@ -244,23 +244,28 @@ def test_spatial_context_matches_reference(golden, oracle_mod):
     r = golden.z("rollouts")
     names = golden.names("rollouts")
     n = len(names)
-    b = _batch(n, autoreset=True)
-    b.load_levels([r["m%d" % i] for i in range(n)])
-    b.assign_levels(np.arange(n))
-    b.enable_spatial_context()
-    b.reset()
-    b.observe()
-    sc = b.spatial_context.cpu().numpy()
-    for i in range(n):
-        assert np.abs(sc[i] - r["sc%d" % i][0]).max() <= 1.2e-7, (names[i], "reset obs", np.abs(sc[i] - r["sc%d" % i][0]).max())
-    acts = torch.from_numpy(np.stack([r["a%d" % i] for i in range(n)], axis=1)).cuda()
     worst = 0.0
-    for s in range(acts.shape[0]):
-        b.step(acts[s])
+    # every lanes-per-env geometry: the nearest-eight selection is split over the lanes of a group (1, 2, 4 lanes own several of
+    # the eight results, 8+ lanes one each)
+    for g, wpb in [(16, 4), (1, 1), (2, 2), (4, 4), (8, 4), (64, 4)]:
+        b = _batch(n, autoreset=True)
+        b.load_levels([r["m%d" % i] for i in range(n)])
+        b.set_launch_geometry(g, wpb)
+        b.assign_levels(np.arange(n))
+        b.enable_spatial_context()
+        b.reset()
+        b.observe()
         sc = b.spatial_context.cpu().numpy()
         for i in range(n):
-            ref = r["sc%d" % i][s + 1]
-            d = np.abs(sc[i] - ref).max()
-            worst = max(worst, d)
-            assert d <= 1.2e-7, (names[i], s, np.nonzero(np.abs(sc[i] - ref) > 1.2e-7)[0][:6])
+            assert np.abs(sc[i] - r["sc%d" % i][0]).max() <= 1.2e-7, (g, names[i], "reset obs", np.abs(sc[i] - r["sc%d" % i][0]).max())
+        acts = torch.from_numpy(np.stack([r["a%d" % i] for i in range(n)], axis=1)).cuda()
+        for s in range(acts.shape[0]):
+            b.step(acts[s])
+            sc = b.spatial_context.cpu().numpy()
+            for i in range(n):
+                ref = r["sc%d" % i][s + 1]
+                d = np.abs(sc[i] - ref).max()
+                worst = max(worst, d)
+                assert d <= 1.2e-7, (g, names[i], s, np.nonzero(np.abs(sc[i] - ref) > 1.2e-7)[0][:6])
+        b.close()
     print("spatial_context worst abs diff %.3g" % worst)
