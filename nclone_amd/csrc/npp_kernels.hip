@@ -473,6 +473,104 @@ DEV QBox make_qbox(double x0, double y0, double x1, double y1) {
     return q;
 }
 
+// The per-segment AABB test of get_single_closest_point (physics.py:150-167) against the ninja's box [x - 10, x + 10] x [y - 10, y + 10],
+// as exact thresholds on x and y: segment bounds are multiples of 12 in [0, 1056], the reference rounds x - 10 and x + 10 before it
+// compares, and rounding is monotone, so "not (b1 < fl(x - 10))" is "x <= b1 + 10" (b1 + 10 is exact and its ulp is at least b1's) and
+// "not (b0 > fl(x + 10))" is "x >= AABB_LO[b0 / 12]", the smallest double whose rounded sum reaches b0 (it lies below b0 - 10 where b0 - 10
+// sits in a lower binade than b0: 8 of the 89 entries).  Generated and checked against the rounded sums on 40 doubles either side of every
+// threshold (tests/test_host_cpu.py repeats the check on the table below); saves the four fp64 additions per candidate and iteration.
+__constant__ double AABB_LO[89] = {
+    -0x1.4000000000000p+3 /* 0: fl(x + 10) >= 0 */,
+    0x1.ffffffffffffcp+0 /* 1: fl(x + 10) >= 12 */,
+    0x1.bffffffffffffp+3 /* 2: fl(x + 10) >= 24 */,
+    0x1.9ffffffffffffp+4 /* 3: fl(x + 10) >= 36 */,
+    0x1.3000000000000p+5 /* 4: fl(x + 10) >= 48 */,
+    0x1.9000000000000p+5 /* 5: fl(x + 10) >= 60 */,
+    0x1.effffffffffffp+5 /* 6: fl(x + 10) >= 72 */,
+    0x1.2800000000000p+6 /* 7: fl(x + 10) >= 84 */,
+    0x1.5800000000000p+6 /* 8: fl(x + 10) >= 96 */,
+    0x1.8800000000000p+6 /* 9: fl(x + 10) >= 108 */,
+    0x1.b800000000000p+6 /* 10: fl(x + 10) >= 120 */,
+    0x1.e7fffffffffffp+6 /* 11: fl(x + 10) >= 132 */,
+    0x1.0c00000000000p+7 /* 12: fl(x + 10) >= 144 */,
+    0x1.2400000000000p+7 /* 13: fl(x + 10) >= 156 */,
+    0x1.3c00000000000p+7 /* 14: fl(x + 10) >= 168 */,
+    0x1.5400000000000p+7 /* 15: fl(x + 10) >= 180 */,
+    0x1.6c00000000000p+7 /* 16: fl(x + 10) >= 192 */,
+    0x1.8400000000000p+7 /* 17: fl(x + 10) >= 204 */,
+    0x1.9c00000000000p+7 /* 18: fl(x + 10) >= 216 */,
+    0x1.b400000000000p+7 /* 19: fl(x + 10) >= 228 */,
+    0x1.cc00000000000p+7 /* 20: fl(x + 10) >= 240 */,
+    0x1.e400000000000p+7 /* 21: fl(x + 10) >= 252 */,
+    0x1.fbfffffffffffp+7 /* 22: fl(x + 10) >= 264 */,
+    0x1.0a00000000000p+8 /* 23: fl(x + 10) >= 276 */,
+    0x1.1600000000000p+8 /* 24: fl(x + 10) >= 288 */,
+    0x1.2200000000000p+8 /* 25: fl(x + 10) >= 300 */,
+    0x1.2e00000000000p+8 /* 26: fl(x + 10) >= 312 */,
+    0x1.3a00000000000p+8 /* 27: fl(x + 10) >= 324 */,
+    0x1.4600000000000p+8 /* 28: fl(x + 10) >= 336 */,
+    0x1.5200000000000p+8 /* 29: fl(x + 10) >= 348 */,
+    0x1.5e00000000000p+8 /* 30: fl(x + 10) >= 360 */,
+    0x1.6a00000000000p+8 /* 31: fl(x + 10) >= 372 */,
+    0x1.7600000000000p+8 /* 32: fl(x + 10) >= 384 */,
+    0x1.8200000000000p+8 /* 33: fl(x + 10) >= 396 */,
+    0x1.8e00000000000p+8 /* 34: fl(x + 10) >= 408 */,
+    0x1.9a00000000000p+8 /* 35: fl(x + 10) >= 420 */,
+    0x1.a600000000000p+8 /* 36: fl(x + 10) >= 432 */,
+    0x1.b200000000000p+8 /* 37: fl(x + 10) >= 444 */,
+    0x1.be00000000000p+8 /* 38: fl(x + 10) >= 456 */,
+    0x1.ca00000000000p+8 /* 39: fl(x + 10) >= 468 */,
+    0x1.d600000000000p+8 /* 40: fl(x + 10) >= 480 */,
+    0x1.e200000000000p+8 /* 41: fl(x + 10) >= 492 */,
+    0x1.ee00000000000p+8 /* 42: fl(x + 10) >= 504 */,
+    0x1.f9fffffffffffp+8 /* 43: fl(x + 10) >= 516 */,
+    0x1.0300000000000p+9 /* 44: fl(x + 10) >= 528 */,
+    0x1.0900000000000p+9 /* 45: fl(x + 10) >= 540 */,
+    0x1.0f00000000000p+9 /* 46: fl(x + 10) >= 552 */,
+    0x1.1500000000000p+9 /* 47: fl(x + 10) >= 564 */,
+    0x1.1b00000000000p+9 /* 48: fl(x + 10) >= 576 */,
+    0x1.2100000000000p+9 /* 49: fl(x + 10) >= 588 */,
+    0x1.2700000000000p+9 /* 50: fl(x + 10) >= 600 */,
+    0x1.2d00000000000p+9 /* 51: fl(x + 10) >= 612 */,
+    0x1.3300000000000p+9 /* 52: fl(x + 10) >= 624 */,
+    0x1.3900000000000p+9 /* 53: fl(x + 10) >= 636 */,
+    0x1.3f00000000000p+9 /* 54: fl(x + 10) >= 648 */,
+    0x1.4500000000000p+9 /* 55: fl(x + 10) >= 660 */,
+    0x1.4b00000000000p+9 /* 56: fl(x + 10) >= 672 */,
+    0x1.5100000000000p+9 /* 57: fl(x + 10) >= 684 */,
+    0x1.5700000000000p+9 /* 58: fl(x + 10) >= 696 */,
+    0x1.5d00000000000p+9 /* 59: fl(x + 10) >= 708 */,
+    0x1.6300000000000p+9 /* 60: fl(x + 10) >= 720 */,
+    0x1.6900000000000p+9 /* 61: fl(x + 10) >= 732 */,
+    0x1.6f00000000000p+9 /* 62: fl(x + 10) >= 744 */,
+    0x1.7500000000000p+9 /* 63: fl(x + 10) >= 756 */,
+    0x1.7b00000000000p+9 /* 64: fl(x + 10) >= 768 */,
+    0x1.8100000000000p+9 /* 65: fl(x + 10) >= 780 */,
+    0x1.8700000000000p+9 /* 66: fl(x + 10) >= 792 */,
+    0x1.8d00000000000p+9 /* 67: fl(x + 10) >= 804 */,
+    0x1.9300000000000p+9 /* 68: fl(x + 10) >= 816 */,
+    0x1.9900000000000p+9 /* 69: fl(x + 10) >= 828 */,
+    0x1.9f00000000000p+9 /* 70: fl(x + 10) >= 840 */,
+    0x1.a500000000000p+9 /* 71: fl(x + 10) >= 852 */,
+    0x1.ab00000000000p+9 /* 72: fl(x + 10) >= 864 */,
+    0x1.b100000000000p+9 /* 73: fl(x + 10) >= 876 */,
+    0x1.b700000000000p+9 /* 74: fl(x + 10) >= 888 */,
+    0x1.bd00000000000p+9 /* 75: fl(x + 10) >= 900 */,
+    0x1.c300000000000p+9 /* 76: fl(x + 10) >= 912 */,
+    0x1.c900000000000p+9 /* 77: fl(x + 10) >= 924 */,
+    0x1.cf00000000000p+9 /* 78: fl(x + 10) >= 936 */,
+    0x1.d500000000000p+9 /* 79: fl(x + 10) >= 948 */,
+    0x1.db00000000000p+9 /* 80: fl(x + 10) >= 960 */,
+    0x1.e100000000000p+9 /* 81: fl(x + 10) >= 972 */,
+    0x1.e700000000000p+9 /* 82: fl(x + 10) >= 984 */,
+    0x1.ed00000000000p+9 /* 83: fl(x + 10) >= 996 */,
+    0x1.f300000000000p+9 /* 84: fl(x + 10) >= 1008 */,
+    0x1.f900000000000p+9 /* 85: fl(x + 10) >= 1020 */,
+    0x1.fefffffffffffp+9 /* 86: fl(x + 10) >= 1032 */,
+    0x1.0280000000000p+10 /* 87: fl(x + 10) >= 1044 */,
+    0x1.0580000000000p+10 /* 88: fl(x + 10) >= 1056 */
+};
+
 template <int K> struct Cand {
     double rx0, ry0, rx1, ry1;   // gathered cell range in pixels: [24 c0, 24 (c1 + 1))
     bool ok;
@@ -481,6 +579,7 @@ template <int K> struct Cand {
     double wx[K], wy[K], l2[K], rl2[K];      // linear: segment vector, |w|^2 and RN(1 / |w|^2)
     double ox[K], oy[K];                     // origin of the owning cell
     double bx0[K], by0[K], bx1[K], by1[K];   // the owning cell's bounds over its segments (:86-105)
+    double tx0[K], tx1[K], ty0[K], ty1[K];   // the segment's AABB as thresholds on the ninja position (AABB_LO above): tx0 <= x <= tx1, ...
 };
 
 template <int G, int K>
@@ -500,6 +599,7 @@ DEV void cand_gather(const Lv &lv, int r, double qx0, double qy0, double qx1, do
         c.s[k] = 0;
         c.x1[k] = 0; c.y1[k] = 0; c.x2[k] = 0; c.y2[k] = 0; c.wx[k] = 0; c.wy[k] = 0; c.l2[k] = 1; c.rl2[k] = 1;
         c.ox[k] = 0; c.oy[k] = 0; c.bx0[k] = 0; c.by0[k] = 0; c.bx1[k] = 0; c.by1[k] = 0;
+        c.tx0[k] = 0; c.tx1[k] = 0; c.ty0[k] = 0; c.ty1[k] = 0;
         if (c.ok && f < total) {
             int xc = c0x, i = a0 + f;
             if (f >= n0) { xc += 1; i = a1 + (f - n0); }
@@ -524,6 +624,16 @@ DEV void cand_gather(const Lv &lv, int r, double qx0, double qy0, double qx1, do
             } else {
                 c.x2[k] = c.x1[k] + (((s >> 6) & 1) ? 24.0 : -24.0);   // p_hor.x (entities.py:113)
                 c.y2[k] = c.y1[k] + (((s >> 7) & 1) ? 24.0 : -24.0);   // p_ver.y (entities.py:114)
+            }
+            {   // AABB of the segment in units of 12 px (entities.py:36-41,119-125): min / max of (x1, x2) and of (y1, y2)
+                const int ux1 = 2 * xc + (int)((s >> 2) & 3), uy1 = 2 * yc + (int)((s >> 4) & 3);
+                int ux2, uy2;
+                if ((s & 1u) == 0) { ux2 = 2 * xc + (int)((s >> 6) & 3); uy2 = 2 * yc + (int)((s >> 8) & 3); }
+                else { ux2 = ux1 + (((s >> 6) & 1) ? 2 : -2); uy2 = uy1 + (((s >> 7) & 1) ? 2 : -2); }
+                const int ulo = ux1 < ux2 ? ux1 : ux2, uhi = ux1 < ux2 ? ux2 : ux1, vlo = uy1 < uy2 ? uy1 : uy2, vhi = uy1 < uy2 ? uy2 : uy1;
+                if (ulo < 0 || uhi > 88 || vlo < 0 || vhi > 88) c.ok = false;   // never produced by the tile tables
+                c.tx0[k] = AABB_LO[ulo < 0 ? 0 : (ulo > 88 ? 88 : ulo)]; c.tx1[k] = 12.0 * uhi + 10.0;
+                c.ty0[k] = AABB_LO[vlo < 0 ? 0 : (vlo > 88 ? 88 : vlo)]; c.ty1[k] = 12.0 * vhi + 10.0;
             }
         }
     }
@@ -667,7 +777,7 @@ DEV double rcp_inrange(double b) {
 // fallback.  CLOSEST(m) fills `m` with the lane's best candidate; everything else is identical.
 struct DepenIO {
     double x, y, vx, vy, fnsx, fnsy, cnsx, cnsy;
-    int fcount, ccount, applied;
+    int fcount, ccount;
 };
 // zoo kernels also carry the crush accumulators (ninja.py:344-346); only a thwump can make them matter
 struct DepenIOZ : DepenIO {
@@ -694,7 +804,6 @@ DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += d
         double dist = sqrt_inrange(dist_sq); /* garbage when tiny: the exit below does not look at it */ \
         double depen_len = NINJA_RADIUS - (back_facing ? -dist : dist); /* dist * result, exactly */   \
         if (none | tiny | (depen_len < 0.0000001)) BREAK;                                              \
-        (io).applied += 1;                                                                             \
         double inv_dist = rcp_inrange(dist);                                                           \
         double norm_dx = ddx * inv_dist, norm_dy = ddy * inv_dist;                                     \
         const double depen_x = norm_dx * depen_len, depen_y = norm_dy * depen_len;                     \
@@ -798,7 +907,8 @@ DEV int collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double x
     IO io;
     io.x = n.x; io.y = n.y; io.vx = n.vx; io.vy = n.vy;
     io.fnsx = fnsx; io.fnsy = fnsy; io.cnsx = cnsx; io.cnsy = cnsy;
-    io.fcount = n.fcount; io.ccount = n.ccount; io.applied = 0;
+    io.fcount = n.fcount; io.ccount = n.ccount;
+    const int counts_before = n.fcount + n.ccount;   // every applied depenetration increments exactly one of the two counters
     crush_in(io, cr);
     STAMP(9);   // sweep + gather setup
     if (fast) {
@@ -816,13 +926,11 @@ DEV int collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double x
             // get_single_closest_point (physics.py:131-180) over the candidate registers
             Best m;
             m.key = __builtin_inf(); m.idx = 0x7fffffff; m.a = 0; m.b = 0;
-            const double qx0 = io.x - NINJA_RADIUS, qy0 = io.y - NINJA_RADIUS, qx1 = io.x + NINJA_RADIUS, qy1 = io.y + NINJA_RADIUS;
 #pragma unroll
             for (int k = 0; k < K; k++)
                 if (k == 0 || (wave_more && ((gp >> k) & 1u))) {   // slot 0 is evaluated unconditionally (masked by gp below)
-                    double bx0 = __builtin_fmin(cd.x1[k], cd.x2[k]), bx1 = __builtin_fmax(cd.x1[k], cd.x2[k]);
-                    double by0 = __builtin_fmin(cd.y1[k], cd.y2[k]), by1 = __builtin_fmax(cd.y1[k], cd.y2[k]);
-                    bool in = ((gp >> k) & 1u) & !((bx1 < qx0) | (bx0 > qx1) | (by1 < qy0) | (by0 > qy1));
+                    // the reference's AABB test on the rounded box x -+ 10, y -+ 10, as exact thresholds (AABB_LO)
+                    bool in = ((gp >> k) & 1u) & (io.x >= cd.tx0[k]) & (io.x <= cd.tx1[k]) & (io.y >= cd.ty0[k]) & (io.y <= cd.ty1[k]);
                     double a, b;
                     bool back = cand_closest_lin(cd, k, io.x, io.y, a, b);
                     if (wave_arcs && (in & ((cd.s[k] & 1u) != 0))) back = cand_closest_arc(cd.s[k], cd.x1[k], cd.y1[k], cd.x2[k], cd.y2[k], io.x, io.y, a, b);
@@ -852,7 +960,7 @@ DEV int collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double x
     fnsx = io.fnsx; fnsy = io.fnsy; cnsx = io.cnsx; cnsy = io.cnsy;
     n.fcount = io.fcount; n.ccount = io.ccount;
     crush_out(io, cr);
-    return io.applied;
+    return io.fcount + io.ccount - counts_before;
 }
 
 // overlap_circle_vs_circle (physics.py:204-207) with an exact-safe early reject

@@ -181,3 +181,35 @@ def test_host_helpers():
     parts = [shard_envs(65536 + 3, r, 8) for r in range(8)]
     assert sum(c for _, c in parts) == 65539 and parts[0][0] == 0
     assert all(parts[k][0] + parts[k][1] == parts[k + 1][0] for k in range(7))
+
+
+def test_aabb_threshold_table_is_exact():
+    """AABB_LO (npp_kernels.hip): entry i is the smallest double x with fl(x + 10) >= 12 i, and 12 i + 10 is the largest with
+    fl(x - 10) <= 12 i -- the thresholds that replace the rounded box of get_single_closest_point's AABB test (physics.py:150-167).
+    Checked on 64 doubles either side of every threshold."""
+    import re
+
+    src = open(os.path.join(ROOT, "nclone_amd", "csrc", "npp_kernels.hip")).read()
+    body = src[src.index("__constant__ double AABB_LO[89] = {"):]
+    body = body[:body.index("};")]
+    vals = [float.fromhex(m) for m in re.findall(r"(-?0x1\.[0-9a-f]+p[+-]\d+)", body)]
+    assert len(vals) == 89
+    ten = np.float64(10.0)
+    for i, t in enumerate(vals):
+        b = np.float64(12.0 * i)
+        x = np.float64(t)
+        for _ in range(64):
+            assert np.float64(x + ten) >= b
+            x = np.nextafter(x, np.inf)
+        x = np.nextafter(np.float64(t), -np.inf)
+        for _ in range(64):
+            assert not (np.float64(x + ten) >= b), i
+            x = np.nextafter(x, -np.inf)
+        x = np.float64(b + ten)
+        for _ in range(64):
+            assert np.float64(x - ten) <= b
+            x = np.nextafter(x, -np.inf)
+        x = np.nextafter(np.float64(b + ten), np.inf)
+        for _ in range(64):
+            assert not (np.float64(x - ten) <= b), i
+            x = np.nextafter(x, np.inf)
