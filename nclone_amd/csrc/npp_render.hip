@@ -875,6 +875,24 @@ __global__ __launch_bounds__(128) void npp_gv_static_v_kernel(const float *gv_h,
 
 constexpr int GV_Q = 512, GV_WORDS = (GV_CELLS + 31) / 32;
 constexpr int GV_PBOX = 32, GV_PATCH = 3072;   // dirty boxes whose pixels are composed up front into LDS patches, patch bytes
+// The cell pass as a kernel of its own (round 2): npp_global_view_kernel's launch lasted as long as its HEAVIEST env (cell pass: 36 k
+// clocks at the median, 250-380 k at the maximum), so an env with at most GV_XQ dirty cells now EXPORTS what the cell pass needs
+// (boxes, patch rectangles, patches, the cell queue; the draw list only if some row may have to compose in place) to a per-env
+// scratch block in HBM, and npp_gv_cells_kernel runs GV_XWAVES wavefronts per env, wavefront j taking the queue slices j, j + GV_XWAVES,
+// ... of GV_ITEM_CELLS cells: the cells of a heavy env are recomputed by several wavefronts at once and the wavefronts of light envs
+// retire after one header read.  (First cut: a global work list with one atomic per item -- 18 k same-address atomics took longer,
+// 280 us, than the cell pass they distributed.)  Same arithmetic, same order per cell.
+// MEASURED AND NOT SHIPPED (-DNPP_GV_SPLIT builds it): 8192 envs on the door levels, fused 223 us; split with one wavefront per env
+// 115 + 122 us, with four 115 + 196 us (32 768 workgroups: ~60 cycles of dispatch each per XCD).  Both halves stay bound by their
+// slowest wavefront -- list + patches up to 149 k clocks, cells up to 202 k (an env with 10 dirty boxes and 110 dirty cells on
+// `switch-simple`) -- and the heavy envs sit late in the grid, so two kernels pay two tails.
+#ifndef NPP_GV_XWAVES
+#define NPP_GV_XWAVES 4
+#endif
+constexpr int GV_XQ = 1024, GV_ITEM_CELLS = 32, GV_BOX_MAX = 192, GV_XWAVES = NPP_GV_XWAVES;
+constexpr int XS_HDR = 0, XS_BOX = 16, XS_PRECT = XS_BOX + GV_BOX_MAX * 8, XS_POFF = XS_PRECT + GV_PBOX * 8, XS_QUEUE = XS_POFF + GV_PBOX * 2,
+              XS_PATCH = XS_QUEUE + GV_XQ * 2, XS_DRAW = XS_PATCH + GV_PATCH, XS_CBOX = XS_DRAW + 224 * 28, XS_END = XS_CBOX + 224 * 4;
+static_assert(XS_DRAW % 16 == 0 && XS_PATCH % 4 == 0 && XS_END <= GV_XSTRIDE, "scratch block layout");
 // LDS of one env (dynamic: the draw list and the box list are sized for the level SET -- the largest number of draw records of
 // a loaded level -- so that ordinary sets leave room for 12 wavefronts per CU instead of 8)
 struct GvLds {
@@ -889,11 +907,11 @@ struct GvLds {
     int *ctr;                     // [0] boxes pushed, [1] cells queued, [2] cells left for another round
     int draw_cap, box_cap;
 };
-__host__ __device__ inline int gv_box_cap(int draw_cap) { return 2 * draw_cap + 2 < 192 ? 2 * draw_cap + 2 : 192; }
+__host__ __device__ inline int gv_box_cap(int draw_cap) { return 2 * draw_cap + 2 < GV_BOX_MAX ? 2 * draw_cap + 2 : GV_BOX_MAX; }
 __host__ __device__ inline size_t gv_lds_bytes(int draw_cap) {
     const int dc4 = (draw_cap + 3) & ~3;
-    return (size_t)dc4 * sizeof(Draw) + (size_t)dc4 * 4 + (size_t)gv_box_cap(draw_cap) * 8 + GV_WORDS * 4 + GV_Q * 2 + GV_PBOX * 8 + GV_PBOX * 2 +
-           GV_PATCH + 16;
+    return ((size_t)dc4 * sizeof(Draw) + (size_t)dc4 * 4 + (size_t)gv_box_cap(draw_cap) * 8 + GV_WORDS * 4 + GV_Q * 2 + GV_PBOX * 8 + GV_PBOX * 2 +
+           GV_PATCH + 16 + 15) & ~(size_t)15;
 }
 __device__ inline GvLds gv_lds_layout(unsigned char *base, int draw_cap) {
     GvLds L;
@@ -947,26 +965,175 @@ __device__ inline void wave_sync() {   // LDS traffic of one wavefront: order it
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One destination cell of the view, recomputed by the 8 lanes of a group (one source row per lane, then an ordered accumulation
+// through the group's lanes): shared by the in-place cell pass of npp_global_view_kernel and by npp_gv_cells_kernel.  Every lane of
+// the calling wavefront whose group has a cell calls it (the shuffles stay inside a group).
+__device__ inline void gv_cell(const GvLds &L, int nd, int nb, const uint8_t *canvas, const uint8_t *pstat, const float *hrow,
+                               uint8_t *out_env, int cell, int lane) {
+    const int sub = lane & 7;
+    const int r = cell / GV_COLS, c = cell - r * GV_COLS;
+    const AreaTab tx = gv_col_tab(c), ty = gv_row_tab(r);
+    const int tx_s1 = tx.s1, tx_s2 = tx.s2, ty_s1 = ty.s1, ty_s2 = ty.s2;
+    const float tx_wh = tx.wh, tx_wm = tx.wm, tx_wt = tx.wt, ty_wh = ty.wh, ty_wm = ty.wm, ty_wt = ty.wt;
+    const int y = ty.a + sub;   // this lane's source row (a destination row spans at most 6)
+    // issued before the mask work so that their latency is hidden: the row's static hs and its static picture slice
+    // (at most 12 pixels -> four aligned dwords; the table is padded by 16 bytes)
+    const int xb0 = tx.a & ~3;
+    const int yl = y < 599 ? y : 599;
+    const float hs_static = hrow[(size_t)yl * GV_COLS + c];
+    const uint32_t *pp = reinterpret_cast<const uint32_t *>(pstat + (size_t)yl * 1056 + xb0);   // dword aligned
+    const uint4 pw = make_uint4(pp[0], pp[1], pp[2], pp[3]);
+    // the drawables that can touch this cell -- needed only by row slices that compose pixels in place (dirty boxes beyond
+    // the patch budget: a crowd of movers), so the scan runs only when some lane of the wavefront asks for it (it was
+    // 20 % of the cell pass when it ran for every cell): the group's lanes share the scan of the cell boxes (four per
+    // 16-byte LDS read), then OR their masks together
+    unsigned long long nm[4] = {0ull, 0ull, 0ull, 0ull};
+    auto scan_cell_masks = [&]() {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned long long m = 0ull;
+            if (w * 64 >= nd) { nm[w] = 0ull; continue; }   // wavefront-uniform
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int chunk = w * 16 + h * 8 + sub;   // drawables 4 chunk .. 4 chunk + 3
+                if (chunk * 4 < nd) {
+                    const uint4 cb = reinterpret_cast<const uint4 *>(L.cbox)[chunk];
+                    const uint32_t q[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int br0 = q[j] & 255u, br1 = (q[j] >> 8) & 255u, bc0 = (q[j] >> 16) & 255u, bc1 = q[j] >> 24;
+                        if (r >= br0 && r <= br1 && c >= bc0 && c <= bc1) m |= 1ull << ((h * 8 + sub) * 4 + j);
+                    }
+                }
+            }
+            uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+#pragma unroll
+            for (int sft = 1; sft < 8; sft <<= 1) {
+                lo |= (uint32_t)__shfl_xor((int)lo, sft, 64);
+                hi |= (uint32_t)__shfl_xor((int)hi, sft, 64);
+            }
+            nm[w] = ((unsigned long long)hi << 32) | lo;
+        }
+    };
+    float hs = 0.f;
+    // the part of this row slice inside dirty boxes: only those pixels are composed again, the others come from the
+    // level's static picture (a pixel outside every dirty box is covered by the same drawables as after the reset, in
+    // the same order)
+    const bool row_live = y < ty.b;
+    int hx0 = 4096, hx1 = -4096;
+    // patched boxes on this row slice: up to four are remembered (two were: a row slice under three boxes -- ninja, switch and door
+    // on a door level -- then composed every pixel in place, and one such env set the duration of the launch)
+    int pn = 0, pi0 = 0, pi1 = 0, pi2 = 0, pi3 = 0;
+    bool inline_compose = false;
+    if (row_live) {
+        for (int b = 0; b < nb; b++) {
+            const short4 bx = L.box[b];
+            if (bx.z >= tx.a && bx.x < tx.b && bx.w >= y && bx.y <= y) {
+                hx0 = hx0 < bx.x ? hx0 : bx.x; hx1 = hx1 > bx.z ? hx1 : bx.z;
+                if (b < GV_PBOX && L.prect[b].z > 0) {
+                    if (pn == 0) pi0 = b;
+                    else if (pn == 1) pi1 = b;
+                    else if (pn == 2) pi2 = b;
+                    else if (pn == 3) pi3 = b;
+                    else inline_compose = true;
+                    pn += 1;
+                } else {
+                    inline_compose = true;
+                }
+            }
+        }
+    }
+    if (__any(inline_compose)) scan_cell_masks();   // whole wavefront: the scan shuffles across the group's lanes
+    if (row_live) {
+        if (hx1 < hx0) {
+            hs = hs_static;
+        } else {
+            // x range [rx, rx + rw) and patch byte of column 0 of this row, per remembered box (rw = 0: not on this row)
+            int rx0 = 0, rw0 = 0, ro0 = 0, rx1 = 0, rw1 = 0, ro1 = 0, rx2 = 0, rw2 = 0, ro2 = 0, rx3 = 0, rw3 = 0, ro3 = 0;
+#define GV_ROW_RECT(I, RX, RW, RO)                                                                                   \
+    if (pn > I) {                                                                                                    \
+        const short4 rr = L.prect[pi##I];                                                                            \
+        RX = rr.x; RW = (y < rr.y || y >= rr.y + rr.w) ? 0 : rr.z; RO = L.poff[pi##I] + (y - rr.y) * rr.z - rr.x;   \
+    }
+            GV_ROW_RECT(0, rx0, rw0, ro0) GV_ROW_RECT(1, rx1, rw1, ro1) GV_ROW_RECT(2, rx2, rw2, ro2) GV_ROW_RECT(3, rx3, rw3, ro3)
+#undef GV_ROW_RECT
+            if (!inline_compose) {
+                for (int x = tx.a; x < tx.b; x++) {
+                    const int o = x - xb0, sh = (o & 3) * 8;
+                    int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
+                    // every patch holds the finished pixel, so whichever covers x will do
+                    if (x >= rx0 && x < rx0 + rw0) pix = L.patch[ro0 + x];
+                    else if (x >= rx1 && x < rx1 + rw1) pix = L.patch[ro1 + x];
+                    else if (x >= rx2 && x < rx2 + rw2) pix = L.patch[ro2 + x];
+                    else if (x >= rx3 && x < rx3 + rw3) pix = L.patch[ro3 + x];
+                    hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pix;
+                }
+            } else {
+                const uint32_t *cp = reinterpret_cast<const uint32_t *>(canvas + (size_t)y * 1056 + xb0);
+                const uint4 cw = make_uint4(cp[0], cp[1], cp[2], cp[3]);
+                for (int x = tx.a; x < tx.b; x++) {
+                    const int o = x - xb0, sh = (o & 3) * 8;
+                    int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
+                    if (x >= hx0 && x <= hx1) {
+                        float eg = 0.f, ea = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            unsigned long long m = nm[w];
+                            while (m) {
+                                const Draw &d = L.draw[w * 64 + __builtin_ctzll(m)];
+                                m &= m - 1;
+                                const int cnt = draw_cover(d, x, y);
+                                if (cnt) {
+                                    float cov = cnt * (1.f / 16.f);
+                                    eg = eg * (1.f - cov) + d.gray * cov;
+                                    ea = ea * (1.f - cov) + cov;
+                                }
+                            }
+                        }
+                        pix = composite(eg, ea, (int)(((o < 4 ? cw.x : (o < 8 ? cw.y : (o < 12 ? cw.z : cw.w))) >> sh) & 0xffu));
+                    }
+                    hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pix;
+                }
+            }
+        }
+    }
+    // ordered vertical accumulation (y ascending) through the group's lanes
+    float acc = 0.f;
+    const int rows = ty.b - ty.a;
+#pragma unroll
+    for (int jr = 0; jr < 8; jr++) {
+        const float h = __shfl(hs, (lane & ~7) + jr, 64);
+        if (jr < rows) acc += tab_w3(ty.a + jr, ty_s1, ty_s2, ty_wh, ty_wm, ty_wt) * h;
+    }
+    if (sub == 0) out_env[cell] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
+}
+
 // Occupancy (round 2): 3 wavefronts per SIMD (136 VGPRs, ~12 KB of LDS per env on the door levels).  Capping the registers at
 // 128 and trimming the LDS for 4 per SIMD was measured and dropped (246 -> 288 us inside the config-5 step): the launch lasts as
 // long as its heaviest env (cells phase p50 36 k clocks, max 250-380 k), not as long as the average one.
 #ifndef NPP_GV_WAVES
 #define NPP_GV_WAVES 3
 #endif
+// wavefronts (= envs) per workgroup: the wavefronts of a workgroup never synchronise with each other, a workgroup only bundles
+// them for the dispatcher
+#ifndef NPP_GV_WPB
+#define NPP_GV_WPB 1
+#endif
+constexpr int GV_WPB = NPP_GV_WPB;
 // One WAVEFRONT per env (the per-env work is small and serial phases dominate: no workgroup barriers, ~20 KB of LDS, many envs
 // in flight per CU).  Phases: copy the level's view; build the current draw list from the level's compact draw-order records
 // and collect the dirty boxes; mark + queue the dirty destination cells; recompute them, 8 lanes per cell (one source row per
 // lane, then an ordered accumulation through lane 0 of the group).
-__global__ __launch_bounds__(64, NPP_GV_WAVES) void npp_global_view_kernel(KernelArgs a, int draw_cap, const uint8_t *gv_p, const float *gv_h,
-                                                              const uint8_t *gv_v, uint8_t *out) {
+__global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_kernel(KernelArgs a, int draw_cap, const uint8_t *gv_p, const float *gv_h,
+                                                              const uint8_t *gv_v, uint8_t *out, unsigned char *xscr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gv_lds[];
-    const GvLds L = gv_lds_layout(gv_lds, draw_cap);
-    const int env = blockIdx.x, lane = threadIdx.x;
+    const int wv = threadIdx.x >> 6;
+    const GvLds L = gv_lds_layout(gv_lds + (size_t)wv * gv_lds_bytes(draw_cap), draw_cap);
+    const int env = blockIdx.x * GV_WPB + wv, lane = threadIdx.x & 63;
     if (env >= a.n) return;
 #ifdef NPP_GV_STATS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     int stat_nq = 0;
-    uint32_t stat_a = 0, stat_b = 0, stat_c = 0, stat_d = 0, stat_e = 0, stat_it = 0;
 #endif
     const int lvl = __builtin_amdgcn_readfirstlane(a.env_level[env]);
     const LevelHdr &H = a.hdr[lvl];
@@ -1103,6 +1270,7 @@ __global__ __launch_bounds__(64, NPP_GV_WAVES) void npp_global_view_kernel(Kerne
                 L.poff[b] = 0;
             }
         }
+        L.ctr[3] = used;
     }
     wave_sync();
     for (int b = 0; b < npb; b++) {
@@ -1175,10 +1343,67 @@ __global__ __launch_bounds__(64, NPP_GV_WAVES) void npp_global_view_kernel(Kerne
     wave_sync();
     const uint8_t *pstat = gv_p + (size_t)lvl * 600 * 1056;
     const float *hrow = gv_h + (size_t)lvl * 600 * GV_COLS;
-    const int grp = lane >> 3, sub = lane & 7;
+    const int grp = lane >> 3;
 #ifdef NPP_GV_STATS
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
 #endif
+    {   // ---- few dirty cells (the usual case): hand the cell pass to npp_gv_cells_kernel
+        int tot = 0;
+        for (int w = lane; w < GV_WORDS; w += 64) tot += __popc(L.dirty[w]);
+#pragma unroll
+        for (int sft = 32; sft; sft >>= 1) tot += __shfl_xor(tot, sft, 64);
+        if (xscr != nullptr && tot <= GV_XQ) {
+            unsigned char *x = xscr + (size_t)env * GV_XSTRIDE;
+            unsigned short *xq = reinterpret_cast<unsigned short *>(x + XS_QUEUE);
+            for (int w = lane; w < GV_WORDS; w += 64) {
+                uint32_t m = L.dirty[w];
+                while (m) {
+                    const int bit = __builtin_ctz(m);
+                    m &= m - 1;
+                    xq[atomicAdd(&L.ctr[1], 1)] = (unsigned short)(w * 32 + bit);
+                }
+            }
+            const int used = L.ctr[3];
+            // may a row have to compose in place?  (a dirty box without a patch, or five boxes on one row slice)
+            const bool inl = nb >= 5 || nb > npb || __any(lane < npb && L.prect[lane < npb ? lane : 0].z == 0);
+            if (lane == 0) *reinterpret_cast<int4 *>(x + XS_HDR) = make_int4(nd, nb, tot, used | (inl ? (int)0x80000000 : 0));
+            {
+                uint2 *xb = reinterpret_cast<uint2 *>(x + XS_BOX);
+                const uint2 *lb = reinterpret_cast<const uint2 *>(L.box);
+                for (int i = lane; i < nb; i += 64) xb[i] = lb[i];
+                uint2 *xr = reinterpret_cast<uint2 *>(x + XS_PRECT);
+                const uint2 *lr = reinterpret_cast<const uint2 *>(L.prect);
+                unsigned short *xo = reinterpret_cast<unsigned short *>(x + XS_POFF);
+                for (int i = lane; i < npb; i += 64) { xr[i] = lr[i]; xo[i] = L.poff[i]; }
+                uint32_t *xp = reinterpret_cast<uint32_t *>(x + XS_PATCH);
+                const uint32_t *lp = reinterpret_cast<const uint32_t *>(L.patch);
+                for (int i = lane; i < (used + 3) / 4; i += 64) xp[i] = lp[i];
+                if (inl) {
+                    uint32_t *xd = reinterpret_cast<uint32_t *>(x + XS_DRAW);
+                    const uint32_t *ld = reinterpret_cast<const uint32_t *>(L.draw);
+                    for (int i = lane; i < nd * 7; i += 64) xd[i] = ld[i];
+                    uint32_t *xc = reinterpret_cast<uint32_t *>(x + XS_CBOX);
+                    const uint32_t *lc = reinterpret_cast<const uint32_t *>(L.cbox);
+                    for (int i = lane; i < ((nd + 3) & ~3); i += 64) xc[i] = lc[i];
+                }
+            }
+#ifdef NPP_GV_STATS
+            wave_sync();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) {   // diagnostic build only: the stamps of this kernel's phases over the view's first bytes (a cell of the
+                               // first row that npp_gv_cells_kernel recomputes overwrites one of them)
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+                uint32_t *dbg = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
+                dbg[0] = (uint32_t)(t1 - t0); dbg[1] = (uint32_t)(t2 - t1); dbg[2] = (uint32_t)(t3 - t2); dbg[3] = (uint32_t)(t4 - t3);
+                dbg[4] = (uint32_t)nd; dbg[5] = (uint32_t)nb; dbg[6] = (uint32_t)tot; dbg[7] = H.n_ent + H.n_mov;
+                for (int k = 8; k < 14; k++) dbg[k] = 0u;
+            }
+#endif
+            return;
+        }
+        if (xscr != nullptr && lane == 0) *reinterpret_cast<int4 *>(xscr + (size_t)env * GV_XSTRIDE + XS_HDR) = make_int4(0, 0, 0, 0);   // nothing exported
+    }
+    // ---- many dirty cells (a crowd of movers, "everything dirty"): the cell pass runs in place
     // the dword copy of the view must have landed before single bytes of it are overwritten
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     for (;;) {
@@ -1200,146 +1425,7 @@ __global__ __launch_bounds__(64, NPP_GV_WAVES) void npp_global_view_kernel(Kerne
 #ifdef NPP_GV_STATS
         stat_nq += nq;
 #endif
-        for (int qi = grp; qi < nq; qi += 8) {
-#ifdef NPP_GV_STATS
-            const unsigned long long u0 = __builtin_amdgcn_s_memtime();
-#endif
-            const int cell = L.queue[qi], r = cell / GV_COLS, c = cell - r * GV_COLS;
-            const AreaTab tx = gv_col_tab(c), ty = gv_row_tab(r);
-            const int tx_s1 = tx.s1, tx_s2 = tx.s2, ty_s1 = ty.s1, ty_s2 = ty.s2;
-            const float tx_wh = tx.wh, tx_wm = tx.wm, tx_wt = tx.wt, ty_wh = ty.wh, ty_wm = ty.wm, ty_wt = ty.wt;
-            const int y = ty.a + sub;   // this lane's source row (a destination row spans at most 6)
-            // issued before the mask work so that their latency is hidden: the row's static hs and its static picture slice
-            // (at most 12 pixels -> four aligned dwords; the table is padded by 16 bytes)
-            const int xb0 = tx.a & ~3;
-            const int yl = y < 599 ? y : 599;
-            const float hs_static = hrow[(size_t)yl * GV_COLS + c];
-            const uint32_t *pp = reinterpret_cast<const uint32_t *>(pstat + (size_t)yl * 1056 + xb0);   // dword aligned
-            const uint4 pw = make_uint4(pp[0], pp[1], pp[2], pp[3]);
-            // the drawables that can touch this cell -- needed only by row slices that compose pixels in place (dirty boxes beyond
-            // the patch budget: a crowd of movers), so the scan runs only when some lane of the wavefront asks for it (it was
-            // 20 % of the cell pass when it ran for every cell): the group's lanes share the scan of the cell boxes (four per
-            // 16-byte LDS read), then OR their masks together
-            unsigned long long nm[4] = {0ull, 0ull, 0ull, 0ull};
-            auto scan_cell_masks = [&]() {
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    unsigned long long m = 0ull;
-                    if (w * 64 >= nd) { nm[w] = 0ull; continue; }   // wavefront-uniform
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int chunk = w * 16 + h * 8 + sub;   // drawables 4 chunk .. 4 chunk + 3
-                        if (chunk * 4 < nd) {
-                            const uint4 cb = reinterpret_cast<const uint4 *>(L.cbox)[chunk];
-                            const uint32_t q[4] = {cb.x, cb.y, cb.z, cb.w};
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const int br0 = q[j] & 255u, br1 = (q[j] >> 8) & 255u, bc0 = (q[j] >> 16) & 255u, bc1 = q[j] >> 24;
-                                if (r >= br0 && r <= br1 && c >= bc0 && c <= bc1) m |= 1ull << ((h * 8 + sub) * 4 + j);
-                            }
-                        }
-                    }
-                    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
-#pragma unroll
-                    for (int sft = 1; sft < 8; sft <<= 1) {
-                        lo |= (uint32_t)__shfl_xor((int)lo, sft, 64);
-                        hi |= (uint32_t)__shfl_xor((int)hi, sft, 64);
-                    }
-                    nm[w] = ((unsigned long long)hi << 32) | lo;
-                }
-            };
-#ifdef NPP_GV_STATS
-            const unsigned long long u1 = __builtin_amdgcn_s_memtime();
-#endif
-            float hs = 0.f;
-            // the part of this row slice inside dirty boxes: only those pixels are composed again, the others come from the
-            // level's static picture (a pixel outside every dirty box is covered by the same drawables as after the reset, in
-            // the same order)
-            const bool row_live = y < ty.b;
-            int hx0 = 4096, hx1 = -4096;
-            int pa = -1, pb = -1;      // patched boxes on this row slice (two are remembered)
-            bool inline_compose = false;
-            if (row_live) {
-                for (int b = 0; b < nb; b++) {
-                    const short4 bx = L.box[b];
-                    if (bx.z >= tx.a && bx.x < tx.b && bx.w >= y && bx.y <= y) {
-                        hx0 = hx0 < bx.x ? hx0 : bx.x; hx1 = hx1 > bx.z ? hx1 : bx.z;
-                        if (b < GV_PBOX && L.prect[b].z > 0) {
-                            if (pa < 0) pa = b;
-                            else if (pb < 0) pb = b;
-                            else inline_compose = true;
-                        } else {
-                            inline_compose = true;
-                        }
-                    }
-                }
-            }
-#ifdef NPP_GV_STATS
-            stat_d += (uint32_t)(__builtin_amdgcn_s_memtime() - u1);
-#endif
-            if (__any(inline_compose)) scan_cell_masks();   // whole wavefront: the scan shuffles across the group's lanes
-            if (row_live) {
-                if (hx1 < hx0) {
-                    hs = hs_static;
-                } else {
-                    short4 ra = make_short4(0, 0, 0, 0), rb = ra;
-                    int oa = 0, ob = 0;
-                    if (pa >= 0) { ra = L.prect[pa]; oa = L.poff[pa] + (y - ra.y) * ra.z - ra.x; if (y < ra.y || y >= ra.y + ra.w) ra.z = 0; }
-                    if (pb >= 0) { rb = L.prect[pb]; ob = L.poff[pb] + (y - rb.y) * rb.z - rb.x; if (y < rb.y || y >= rb.y + rb.w) rb.z = 0; }
-                    if (!inline_compose) {
-                        for (int x = tx.a; x < tx.b; x++) {
-                            const int o = x - xb0, sh = (o & 3) * 8;
-                            int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
-                            if (x >= ra.x && x < ra.x + ra.z) pix = L.patch[oa + x];
-                            else if (x >= rb.x && x < rb.x + rb.z) pix = L.patch[ob + x];
-                            hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pix;
-                        }
-                    } else {
-                        const uint32_t *cp = reinterpret_cast<const uint32_t *>(canvas + (size_t)y * 1056 + xb0);
-                        const uint4 cw = make_uint4(cp[0], cp[1], cp[2], cp[3]);
-                        for (int x = tx.a; x < tx.b; x++) {
-                            const int o = x - xb0, sh = (o & 3) * 8;
-                            int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
-                            if (x >= hx0 && x <= hx1) {
-                                float eg = 0.f, ea = 0.f;
-#pragma unroll
-                                for (int w = 0; w < 4; w++) {
-                                    unsigned long long m = nm[w];
-                                    while (m) {
-                                        const Draw &d = L.draw[w * 64 + __builtin_ctzll(m)];
-                                        m &= m - 1;
-                                        const int cnt = draw_cover(d, x, y);
-                                        if (cnt) {
-                                            float cov = cnt * (1.f / 16.f);
-                                            eg = eg * (1.f - cov) + d.gray * cov;
-                                            ea = ea * (1.f - cov) + cov;
-                                        }
-                                    }
-                                }
-                                pix = composite(eg, ea, (int)(((o < 4 ? cw.x : (o < 8 ? cw.y : (o < 12 ? cw.z : cw.w))) >> sh) & 0xffu));
-                            }
-                            hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pix;
-                        }
-                    }
-                }
-            }
-#ifdef NPP_GV_STATS
-            const unsigned long long u2 = __builtin_amdgcn_s_memtime();
-#endif
-            // ordered vertical accumulation (y ascending) through the group's lanes
-            float acc = 0.f;
-            const int rows = ty.b - ty.a;
-#pragma unroll
-            for (int jr = 0; jr < 8; jr++) {
-                const float h = __shfl(hs, (lane & ~7) + jr, 64);
-                if (jr < rows) acc += tab_w3(ty.a + jr, ty_s1, ty_s2, ty_wh, ty_wm, ty_wt) * h;
-            }
-            if (sub == 0) out[(size_t)env * GV_CELLS + cell] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
-#ifdef NPP_GV_STATS
-            const unsigned long long u3 = __builtin_amdgcn_s_memtime();
-            stat_a += (uint32_t)(u1 - u0); stat_b += (uint32_t)(u2 - u1); stat_c += (uint32_t)(u3 - u2); stat_it += 1;
-#endif
-        }
+        for (int qi = grp; qi < nq; qi += 8) gv_cell(L, nd, nb, canvas, pstat, hrow, out + (size_t)env * GV_CELLS, L.queue[qi], lane);
         if (!more) break;
         wave_sync();
         if (lane == 0) { L.ctr[1] = 0; L.ctr[2] = 0; }
@@ -1353,7 +1439,79 @@ __global__ __launch_bounds__(64, NPP_GV_WAVES) void npp_global_view_kernel(Kerne
         uint32_t *dbg = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
         dbg[0] = (uint32_t)(t1 - t0); dbg[1] = (uint32_t)(t2 - t1); dbg[2] = (uint32_t)(t3 - t2); dbg[3] = (uint32_t)(t4 - t3);
         dbg[4] = (uint32_t)nd; dbg[5] = (uint32_t)nb; dbg[6] = (uint32_t)stat_nq; dbg[7] = H.n_ent + H.n_mov;
-        dbg[8] = stat_a; dbg[9] = stat_b; dbg[10] = stat_c; dbg[11] = stat_d; dbg[12] = stat_e; dbg[13] = stat_it;
+        for (int k = 8; k < 14; k++) dbg[k] = 0u;
+    }
+#endif
+}
+
+// The cell pass of the envs that exported it: GV_XWAVES wavefronts per env; wavefront j stages the env's boxes / patches from its
+// scratch block once and runs the same per-cell code as the in-place pass on the queue slices j, j + GV_XWAVES, ...
+struct GvCellsLds {
+    Draw draw[224];
+    uchar4 cbox[224];
+    short4 box[GV_BOX_MAX];
+    short4 prect[GV_PBOX];
+    unsigned short poff[GV_PBOX];
+    unsigned short queue[GV_ITEM_CELLS];
+    __attribute__((aligned(4))) unsigned char patch[GV_PATCH];
+};
+__global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_gv_cells_kernel(KernelArgs a, const uint8_t *gv_p, const float *gv_h,
+                                                                         const unsigned char *xscr, uint8_t *out) {
+    __shared__ __attribute__((aligned(16))) GvCellsLds SS[GV_WPB];
+    GvCellsLds &S = SS[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63, grp = lane >> 3;
+    const int gw = blockIdx.x * GV_WPB + (threadIdx.x >> 6);
+    const int env = gw / GV_XWAVES, j = gw - env * GV_XWAVES;
+    if (env >= a.n) return;
+#ifdef NPP_GV_STATS
+    const unsigned long long k2t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const unsigned char *x = xscr + (size_t)env * GV_XSTRIDE;
+    const int4 hd = *reinterpret_cast<const int4 *>(x + XS_HDR);
+    const int nd = hd.x, nb = hd.y, nq = hd.z, used = hd.w & 0xffff;
+    if (j * GV_ITEM_CELLS >= nq) return;   // nothing for this wavefront (also: the env ran its cell pass in place, nq = 0)
+    const bool inl = hd.w < 0;
+    GvLds L;
+    L.draw = S.draw; L.cbox = S.cbox; L.box = S.box; L.prect = S.prect; L.poff = S.poff; L.queue = S.queue; L.patch = S.patch;
+    L.dirty = nullptr; L.ctr = nullptr; L.draw_cap = 224; L.box_cap = GV_BOX_MAX;
+    const int npb = nb < GV_PBOX ? nb : GV_PBOX;
+    {
+        const uint2 *xb = reinterpret_cast<const uint2 *>(x + XS_BOX);
+        uint2 *lb = reinterpret_cast<uint2 *>(S.box);
+        for (int i = lane; i < nb; i += 64) lb[i] = xb[i];
+        const uint2 *xr = reinterpret_cast<const uint2 *>(x + XS_PRECT);
+        uint2 *lr = reinterpret_cast<uint2 *>(S.prect);
+        const unsigned short *xo = reinterpret_cast<const unsigned short *>(x + XS_POFF);
+        for (int i = lane; i < npb; i += 64) { lr[i] = xr[i]; S.poff[i] = xo[i]; }
+        const uint32_t *xp = reinterpret_cast<const uint32_t *>(x + XS_PATCH);
+        uint32_t *lp = reinterpret_cast<uint32_t *>(S.patch);
+        for (int i = lane; i < (used + 3) / 4; i += 64) lp[i] = xp[i];
+        if (inl) {
+            const uint32_t *xd = reinterpret_cast<const uint32_t *>(x + XS_DRAW);
+            uint32_t *ld = reinterpret_cast<uint32_t *>(S.draw);
+            for (int i = lane; i < nd * 7; i += 64) ld[i] = xd[i];
+            const uint32_t *xc = reinterpret_cast<const uint32_t *>(x + XS_CBOX);
+            uint32_t *lc = reinterpret_cast<uint32_t *>(S.cbox);
+            for (int i = lane; i < ((nd + 3) & ~3); i += 64) lc[i] = xc[i];
+        }
+    }
+    const int lvl = __builtin_amdgcn_readfirstlane(a.env_level[env]);
+    const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
+    const uint8_t *pstat = gv_p + (size_t)lvl * 600 * 1056;
+    const float *hrow = gv_h + (size_t)lvl * 600 * GV_COLS;
+    const unsigned short *xq = reinterpret_cast<const unsigned short *>(x + XS_QUEUE);
+    for (int q0 = j * GV_ITEM_CELLS; q0 < nq; q0 += GV_XWAVES * GV_ITEM_CELLS) {
+        const int ncell = nq - q0 < GV_ITEM_CELLS ? nq - q0 : GV_ITEM_CELLS;
+        wave_sync();   // the previous slice's cells are done with the queue
+        if (lane < ncell) S.queue[lane] = xq[q0 + lane];
+        wave_sync();
+        for (int qi = grp; qi < ncell; qi += 8) gv_cell(L, nd, nb, canvas, pstat, hrow, out + (size_t)env * GV_CELLS, S.queue[qi], lane);
+    }
+#ifdef NPP_GV_STATS
+    wave_sync();
+    if (lane == 0 && j == 0) {   // diagnostic build only: this wavefront's duration, dirty cells, in-place flag
+        uint32_t *dbg = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
+        dbg[8] = (uint32_t)(__builtin_amdgcn_s_memtime() - k2t0); dbg[9] = (uint32_t)nq; dbg[10] = inl ? 1u : 0u; dbg[11] = (uint32_t)used;
     }
 #endif
 }
@@ -1418,10 +1576,16 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
 }
 
 hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_t *gv_p, const float *gv_h, const uint8_t *gv_v,
-                              uint8_t *d_out, hipStream_t s) {
+                              uint8_t *d_out, unsigned char *xscr, hipStream_t s) {
     int cap = max_records + 1;   // + the ninja
     cap = cap < 16 ? 16 : (cap > GV_DRAW ? GV_DRAW : cap);
-    hipLaunchKernelGGL(npp_global_view_kernel, dim3(a.n), dim3(64), gv_lds_bytes(cap), s, a, cap, gv_p, gv_h, gv_v, d_out);
+#ifndef NPP_GV_SPLIT
+    xscr = nullptr;   // shipped: the whole cell pass inside the first kernel (the split variant is an A/B build, see above)
+#endif
+    hipLaunchKernelGGL(npp_global_view_kernel, dim3((a.n + GV_WPB - 1) / GV_WPB), dim3(64 * GV_WPB), GV_WPB * gv_lds_bytes(cap), s, a, cap, gv_p, gv_h,
+                       gv_v, d_out, xscr);
+    if (xscr)
+        hipLaunchKernelGGL(npp_gv_cells_kernel, dim3((a.n * GV_XWAVES + GV_WPB - 1) / GV_WPB), dim3(64 * GV_WPB), 0, s, a, gv_p, gv_h, xscr, d_out);
     return hipGetLastError();
 }
 

@@ -361,3 +361,44 @@ def test_player_frame_config3_full_size(golden):
         ref, edge = player_frame(levels[lvl[e]], b.dump_entities(int(e)), f[e, 0], f[e, 1], centered=False)
         d = np.abs(frames[e].astype(np.int64) - ref.astype(np.int64))
         assert len(np.argwhere((d > 0) & ~edge)) == 0 and d.max(initial=0) <= 64 and d.mean() < 2.0, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("centered", [False, True])
+def test_player_frame_windows_at_the_canvas_edges(golden, centered):
+    """Windows clipped by the canvas on every side (fewer rows and / or fewer columns than 84: padding rows in the strip pass, the
+    generic span path for narrow windows) on mine-dense levels: spawn positions moved to the map's edges and corners, frame of the
+    reset state against the numpy restatement (same tolerance as the other raster tests; raster parity itself is unpinned)."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import mine_levels
+    from tests.raster_ref import player_frame
+
+    base, _ = mine_levels()
+    dense = sorted(range(len(base)), key=lambda i: -len(base[i]))[:3]
+    spots = [(30, 30), (300, 30), (30, 300), (620, 300), (300, 570), (1026, 30), (1026, 570), (30, 570), (48, 576), (558, 42), (642, 300),
+             (528, 288), (41, 41), (43, 43)]
+    levels = []
+    for li in dense:
+        for (x, y) in spots:
+            m = np.array(base[li], dtype=np.float64).copy()
+            m[1231], m[1232] = x // 6, y // 6
+            levels.append(m)
+    n = len(levels)
+    b = NppBatch(n, autoreset=False, frame_centered=centered)
+    b.load_levels(levels)
+    b.assign_levels(np.arange(n))
+    b.reset()
+    out = torch.zeros((n, 84, 84), dtype=torch.uint8, device="cuda")
+    b.render_player_frame(out)
+    frames = out.cpu().numpy()
+    f, _ = b.dump_state()
+    shapes = set()
+    for e in range(n):
+        ref, edge = player_frame(levels[e], b.dump_entities(e), f[e, 0], f[e, 1], centered=centered)
+        got = frames[e].astype(np.int64)
+        d = np.abs(got - ref.astype(np.int64))
+        bad = np.argwhere((d > 0) & ~edge)
+        assert len(bad) == 0, (e, f[e, :2], [(tuple(p), int(got[tuple(p)]), int(ref[tuple(p)])) for p in bad[:8]])
+        assert d.max(initial=0) <= 64 and d.mean() < 2.0
+        shapes.add((int((ref.sum(axis=1) > 0).sum()) < 84, int((ref.sum(axis=0) > 0).sum()) < 84))
+    assert len(shapes) >= 3   # full frames, frames with padding rows, frames with padding columns

@@ -34,12 +34,15 @@ ev[1].record(b.stream)
 torch.cuda.synchronize()
 print("launch us", ev[0].elapsed_time(ev[1]) * 100)
 d = b.out.t["global_view"].reshape(n, -1)[:, :64].contiguous().cpu().numpy().view(np.uint32)
-names = ["copy", "list", "mark", "cells", "nd", "nb", "nq", "records", "cell:mask", "cell:rows", "cell:acc", "rows:boxes", "rows:loadwait", "iterations"]
+names = ["copy", "list", "mark", "cells/export", "nd", "nb", "nq", "records", "K2 wave 0 clocks", "K2 nq", "K2 in-place flag", "K2 patch bytes"]
 for i, k in enumerate(names):
     col = d[:, i].astype(np.float64)
     print("%-8s mean %10.1f  p50 %8.0f  p95 %8.0f  max %8.0f" % (k, col.mean(), np.percentile(col, 50), np.percentile(col, 95), col.max()))
 lv = (np.arange(n) // 64) % len(levels)
 tot = d[:, :4].sum(axis=1).astype(np.float64)
 worst = np.argsort(-np.array([tot[lv == i].mean() for i in range(len(levels))]))[:5]
+k2 = d[:, 8].astype(np.float64)
+top = np.argsort(-k2)[:8]
+print("slowest cell-pass wavefronts:", [(int(e), tags[lv[e]], int(k2[e]), "nq", int(d[e, 9]), "inl", int(d[e, 10]), "nb", int(d[e, 5])) for e in top])
 for i in worst:
     print("level", tags[i], "ticks", tot[lv == i].mean(), "nq", d[lv == i, 6].mean(), "nb", d[lv == i, 5].mean(), "nd", d[lv == i, 4].mean())

@@ -13,7 +13,7 @@ from nclone_amd.engine import NppBatch
 wl = sys.argv[1] if len(sys.argv) > 1 else "doors"
 levels, tags = {"c0": level_sets.curriculum0_levels, "mines": level_sets.mine_levels, "doors": level_sets.door_levels,
                 "zoo": level_sets.zoo_levels, "c3mixed": level_sets.c3_mixed_levels}[wl]()
-n = 8192
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 b = NppBatch(n, autoreset=True, outputs=("global_view",))
 b.load_levels(levels)
 b.assign_levels((np.arange(n) // 64) % len(levels))
