@@ -46,6 +46,8 @@ struct npp_handle_s {
     float *d_gv_h = nullptr;       // global_view: per-level picture / horizontal sums / view of the level right after a reset
     uint8_t *d_gv_v = nullptr, *d_gv_p = nullptr;
     unsigned char *d_gv_x = nullptr;   // global_view: per-env scratch of the split cell pass
+    uint32_t *d_gv_order = nullptr, *d_gv_cost = nullptr;   // global_view: heavy-first launch order and the per-env cost it is built from
+    long gv_launches = 0;
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
     unsigned char *d_rblob = nullptr;
@@ -229,6 +231,12 @@ int ensure_gv(npp_handle h) {
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_gv_static(a, (int)nl, h->d_gv_p, gh, h->d_gv_v, h->stream));
     h->d_gv_h = gh;
+    if (!h->d_gv_order) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_gv_order, (size_t)h->n * sizeof(uint32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_gv_cost, (size_t)h->n * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemsetAsync(h->d_gv_cost, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
+        h->gv_launches = 0;   // the first launch builds an order (any permutation) from the zero costs
+    }
 #ifdef NPP_GV_SPLIT
     if (!h->d_gv_x) {   // (A/B builds of the split cell pass) sized by the number of envs, not by the level set: kept across npp_load_levels
         HIP_TRY(h, hipMalloc((void **)&h->d_gv_x, (size_t)h->n * GV_XSTRIDE));
@@ -335,7 +343,7 @@ int npp_destroy(npp_handle h) {
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
     hipFree(h->d_gv_h); hipFree(h->d_gv_v); hipFree(h->d_gv_p);
-    hipFree(h->d_gv_x);
+    hipFree(h->d_gv_x); hipFree(h->d_gv_order); hipFree(h->d_gv_cost);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -754,7 +762,8 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     KernelArgs a = base_args(h);
     int max_records = 0;
     for (const LevelHdr &lh : h->hdrs) max_records = std::max(max_records, (int)(lh.n_door + lh.n_ent + lh.n_mov));
-    HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->stream));
+    HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost,
+                                  (h->gv_launches++ % 4) < 2, h->stream));   // the order is rebuilt on launches 0, 1, 4, 5, 8, ... (costs exist from launch 1 on)
     return NPP_OK;
 }
 

@@ -146,8 +146,10 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
 // max_records: the largest number of draw records (closed-door strokes + entities + movers) of a loaded level; sizes the LDS
 // xscr: the per-env scratch of the split cell pass (GV_XSTRIDE bytes per env); null keeps the whole cell pass inside the first kernel
 constexpr size_t GV_XSTRIDE = 14336;
+// order / cost: u32[n] each -- the launch order of the envs (heaviest first) and the clocks every env's wavefront took; `reorder`
+// rebuilds the order from the costs before the launch (null order = env order)
 hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_t *gv_p, const float *gv_h, const uint8_t *gv_v,
-                              uint8_t *d_out, unsigned char *xscr, hipStream_t s);
+                              uint8_t *d_out, unsigned char *xscr, uint32_t *order, uint32_t *cost, int reorder, hipStream_t s);
 // per-level static tables of global_view (the level right after a reset; needs the tile canvas): gv_p u8[n_levels][600][1056]
 // (+ 16 bytes) picture, gv_h f32[n_levels][600][100] horizontal sums, gv_v u8[n_levels][176][100] view
 hipError_t launch_gv_static(const KernelArgs &a, int n_levels, uint8_t *gv_p, float *gv_h, uint8_t *gv_v, hipStream_t s);

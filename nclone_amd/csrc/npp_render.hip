@@ -1125,12 +1125,16 @@ constexpr int GV_WPB = NPP_GV_WPB;
 // and collect the dirty boxes; mark + queue the dirty destination cells; recompute them, 8 lanes per cell (one source row per
 // lane, then an ordered accumulation through lane 0 of the group).
 __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_kernel(KernelArgs a, int draw_cap, const uint8_t *gv_p, const float *gv_h,
-                                                              const uint8_t *gv_v, uint8_t *out, unsigned char *xscr) {
+                                                              const uint8_t *gv_v, uint8_t *out, unsigned char *xscr,
+                                                              const uint32_t *order, uint32_t *cost) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gv_lds[];
     const int wv = threadIdx.x >> 6;
     const GvLds L = gv_lds_layout(gv_lds + (size_t)wv * gv_lds_bytes(draw_cap), draw_cap);
-    const int env = blockIdx.x * GV_WPB + wv, lane = threadIdx.x & 63;
-    if (env >= a.n) return;
+    const int slot = blockIdx.x * GV_WPB + wv, lane = threadIdx.x & 63;
+    if (slot >= a.n) return;
+    // heavy envs first: `order` lists the envs by the clocks their wavefront took in an earlier launch (npp_gv_order_kernel)
+    const int env = order ? (int)order[slot] : slot;
+    const unsigned long long cost_t0 = __builtin_amdgcn_s_memtime();
 #ifdef NPP_GV_STATS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     int stat_nq = 0;
@@ -1442,6 +1446,33 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
         for (int k = 8; k < 14; k++) dbg[k] = 0u;
     }
 #endif
+    if (cost && lane == 0) cost[env] = (uint32_t)(__builtin_amdgcn_s_memtime() - cost_t0);
+}
+
+// Launch order of npp_global_view_kernel: envs binned by the clocks of their last measured wavefront (128 logarithmic bins, four per
+// octave), heaviest bin first.  The launch lasts about as long as its slowest wavefronts; in env order those sit anywhere in the grid
+// (the cost follows the level and the env's state, both of which change slowly), listed first they start at time zero: 223 -> 141 us
+// on the door levels.  (A two-group variant -- above 1.5 x the mean first, both groups in env order -- was stable but weaker, 164 us,
+// and its serial scan cost 21 us.)  One workgroup; a pure scheduling aid: every env appears exactly once whatever the costs are, and
+// the order inside a bin is whatever the atomics make it.
+__device__ inline int gv_cost_bin(uint32_t c) {
+    if (c < 16u) return 0;
+    const int msb = 31 - __builtin_clz(c);                 // 4 .. 31
+    return (msb - 4) * 4 + (int)((c >> (msb - 2)) & 3u) + 1;   // 1 .. 112
+}
+__global__ __launch_bounds__(1024) void npp_gv_order_kernel(const uint32_t *cost, uint32_t *order, int n) {
+    __shared__ int hist[128];
+    __shared__ int base[128];
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += blockDim.x) atomicAdd(&hist[gv_cost_bin(cost[e])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 127; b >= 0; b--) { base[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += blockDim.x) order[atomicAdd(&base[gv_cost_bin(cost[e])], 1)] = (uint32_t)e;
 }
 
 // The cell pass of the envs that exported it: GV_XWAVES wavefronts per env; wavefront j stages the env's boxes / patches from its
@@ -1576,14 +1607,15 @@ hipError_t launch_render(const KernelArgs &a, uint8_t *d_out, int centered, hipS
 }
 
 hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_t *gv_p, const float *gv_h, const uint8_t *gv_v,
-                              uint8_t *d_out, unsigned char *xscr, hipStream_t s) {
+                              uint8_t *d_out, unsigned char *xscr, uint32_t *order, uint32_t *cost, int reorder, hipStream_t s) {
     int cap = max_records + 1;   // + the ninja
     cap = cap < 16 ? 16 : (cap > GV_DRAW ? GV_DRAW : cap);
 #ifndef NPP_GV_SPLIT
     xscr = nullptr;   // shipped: the whole cell pass inside the first kernel (the split variant is an A/B build, see above)
 #endif
+    if (order && reorder) hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, a.n);
     hipLaunchKernelGGL(npp_global_view_kernel, dim3((a.n + GV_WPB - 1) / GV_WPB), dim3(64 * GV_WPB), GV_WPB * gv_lds_bytes(cap), s, a, cap, gv_p, gv_h,
-                       gv_v, d_out, xscr);
+                       gv_v, d_out, xscr, order, cost);
     if (xscr)
         hipLaunchKernelGGL(npp_gv_cells_kernel, dim3((a.n * GV_XWAVES + GV_WPB - 1) / GV_WPB), dim3(64 * GV_WPB), 0, s, a, gv_p, gv_h, xscr, d_out);
     return hipGetLastError();
