@@ -48,6 +48,9 @@ struct npp_handle_s {
     unsigned char *d_gv_x = nullptr;   // global_view: per-env scratch of the split cell pass
     uint32_t *d_gv_order = nullptr, *d_gv_cost = nullptr;   // global_view: heavy-first launch order and the per-env cost it is built from
     long gv_launches = 0;
+    uint32_t *d_wg_order = nullptr, *d_wg_cost = nullptr;   // npp_step: heavy-first workgroup order and the per-block cost behind it
+    int wg_blocks = 0;
+    long step_launches = 0;
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
     unsigned char *d_rblob = nullptr;
@@ -343,7 +346,7 @@ int npp_destroy(npp_handle h) {
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
     hipFree(h->d_gv_h); hipFree(h->d_gv_v); hipFree(h->d_gv_p);
-    hipFree(h->d_gv_x); hipFree(h->d_gv_order); hipFree(h->d_gv_cost);
+    hipFree(h->d_gv_x); hipFree(h->d_gv_order); hipFree(h->d_gv_cost); hipFree(h->d_wg_order); hipFree(h->d_wg_cost);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -642,6 +645,25 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
     a.n_ticks = frame_skip;
     a.mode = 0;
     fill_out(a, out);
+    {   // heavy-first workgroup order: rebuilt from the per-block costs every 16th launch (and whenever the launch geometry changes)
+        const int epb = (64 / (h->geo_g > 0 ? h->geo_g : 1)) * (h->geo_wpb > 0 ? h->geo_wpb : 1);
+        const int blocks = (h->n + epb - 1) / epb;
+        if (!h->d_wg_order) {
+            HIP_TRY(h, hipMalloc((void **)&h->d_wg_order, (size_t)h->n * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_wg_cost, (size_t)h->n * sizeof(uint32_t)));
+            h->wg_blocks = 0;
+        }
+        const bool fresh = blocks != h->wg_blocks;
+        if (fresh || h->step_launches % 16 == 0) {
+            if (fresh) HIP_TRY(h, hipMemsetAsync(h->d_wg_cost, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
+            HIP_TRY(h, launch_cost_order(h->d_wg_cost, h->d_wg_order, blocks, h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->d_wg_cost, 0, (size_t)blocks * sizeof(uint32_t), h->stream));   // costs are maxima over the next 16 launches
+            h->wg_blocks = blocks;
+        }
+        h->step_launches++;
+        a.wg_order = h->d_wg_order;
+        a.wg_cost = h->d_wg_cost;
+    }
     HIP_TRY(h, launch_step(a, h->stream));
     return NPP_OK;
 }

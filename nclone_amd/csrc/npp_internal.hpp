@@ -108,6 +108,10 @@ struct KernelArgs {
     int zoo_active;       // 1: some env currently plays a level with zoo entities -> the zoo step kernel runs
     int reset_fresh;      // reset kernel: 1 = this reset is the first creation after a (re)assignment of levels
     int fast_reset;       // reset kernel: this reset is a Simulator.fast_reset; step kernels: auto-resets are fast resets
+    // npp_step only (null elsewhere): heavy-first launch order of the workgroups -- wg_order[blockIdx.x] is the block of envs this
+    // workgroup steps, wg_cost[block] the shader clocks its last launch took (launch_cost_order rebuilds the order from the costs)
+    const uint32_t *wg_order;
+    uint32_t *wg_cost;
     StepOut out;
 };
 
@@ -162,6 +166,8 @@ hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned 
 // envs selected by a.reset_mask (NULL = all): key / cache <- the snapshot's, or "no cached vector" when src_key == NULL
 hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, const float *src_cache, uint32_t *key, float *cache,
                                 hipStream_t s);
+// order <- the indices 0 .. n - 1 sorted by cost, heaviest first (128 logarithmic bins; any costs give a permutation)
+hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, hipStream_t s);
 hipError_t launch_tile_tables(hipStream_t s);   // per-device tile gray tables of the player_frame kernel
 hipError_t launch_tile_canvas(const LevelHdr *d_hdr, const unsigned char *d_blob, uint8_t *d_canvas, int n_levels, hipStream_t s);
 

@@ -1574,7 +1574,11 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     const int r = lane & (G - 1);          // rank inside the env's lane group
     const int epb = EPW * (blockDim.x >> 6);   // envs per workgroup
     const int eib = wave * EPW + lane / G;     // env index inside the workgroup
-    const int env0 = blockIdx.x * epb;
+    // heavy-first (npp_step): the workgroups whose envs iterated longest in an earlier launch are dispatched first, so that the
+    // chain that decides the launch's duration starts at time zero instead of in the second residency round
+    const int blk = a.wg_order ? (int)a.wg_order[blockIdx.x] : (int)blockIdx.x;
+    const unsigned long long wg_t0 = a.wg_cost ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int env0 = blk * epb;
     const int env = env0 + eib;
     const bool valid = env < a.n;
     const int e = valid ? env : a.n - 1;
@@ -1792,6 +1796,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         }
     }
     STAMP(8);
+    if (a.wg_cost && lane == 0) atomicMax(&a.wg_cost[blk], (uint32_t)(__builtin_amdgcn_s_memtime() - wg_t0));   // slowest wavefront of the block
 #ifdef NPP_STAMPS
     if (lane == 0) {
         unsigned gw = blockIdx.x * (blockDim.x >> 6) + wave;

@@ -1621,6 +1621,11 @@ hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_
     return hipGetLastError();
 }
 
+hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, hipStream_t s) {
+    hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_gv_static(const KernelArgs &a, int n_levels, uint8_t *gv_p, float *gv_h, uint8_t *gv_v, hipStream_t s) {
     hipLaunchKernelGGL(npp_gv_static_h_kernel, dim3(600, n_levels), dim3(256), 0, s, a, gv_p, gv_h);
     hipLaunchKernelGGL(npp_gv_static_v_kernel, dim3(GV_ROWS, n_levels), dim3(128), 0, s, gv_h, gv_v);
