@@ -48,6 +48,8 @@ struct npp_handle_s {
     unsigned char *d_gv_x = nullptr;   // global_view: per-env scratch of the split cell pass
     uint32_t *d_gv_order = nullptr, *d_gv_cost = nullptr;   // global_view: heavy-first launch order and the per-env cost it is built from
     long gv_launches = 0;
+    uint32_t *d_pf_order = nullptr, *d_pf_cost = nullptr;   // npp_render_player_frame: heavy-first env order and the per-env cost behind it
+    long pf_launches = 0;
     uint32_t *d_wg_order = nullptr, *d_wg_cost = nullptr;   // npp_step: heavy-first workgroup order and the per-block cost behind it
     int wg_blocks = 0;
     long step_launches = 0;
@@ -346,7 +348,7 @@ int npp_destroy(npp_handle h) {
     hipFree(h->d_f64); hipFree(h->d_u32); hipFree(h->d_ent); hipFree(h->d_env_level); hipFree(h->d_trunc);
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
     hipFree(h->d_gv_h); hipFree(h->d_gv_v); hipFree(h->d_gv_p);
-    hipFree(h->d_gv_x); hipFree(h->d_gv_order); hipFree(h->d_gv_cost); hipFree(h->d_wg_order); hipFree(h->d_wg_cost);
+    hipFree(h->d_gv_x); hipFree(h->d_gv_order); hipFree(h->d_gv_cost); hipFree(h->d_wg_order); hipFree(h->d_wg_cost); hipFree(h->d_pf_order); hipFree(h->d_pf_cost);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -715,6 +717,18 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     ON_DEVICE(h);
     if (int rc = ensure_canvas(h)) return rc;
     KernelArgs a = base_args(h);
+    {   // heavy-first env order, rebuilt from the last launch's per-env clocks on every 8th launch
+        if (!h->d_pf_order) {
+            HIP_TRY(h, hipMalloc((void **)&h->d_pf_order, (size_t)h->n * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_pf_cost, (size_t)h->n * sizeof(uint32_t)));
+            HIP_TRY(h, hipMemsetAsync(h->d_pf_cost, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
+            h->pf_launches = 0;
+        }
+        if (h->pf_launches % 8 < 2) HIP_TRY(h, launch_cost_order(h->d_pf_cost, h->d_pf_order, h->n, h->stream));
+        h->pf_launches++;
+        a.wg_order = h->d_pf_order;
+        a.wg_cost = h->d_pf_cost;
+    }
     HIP_TRY(h, launch_render(a, d_out, (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0, h->stream));
     return NPP_OK;
 }

@@ -688,8 +688,10 @@ __device__ inline uint32_t pixel_full(const FrameLds &L, const Window &wd, const
 #endif
 __global__ __launch_bounds__(256, NPP_RENDER_OCC) void npp_render_kernel(KernelArgs a, uint8_t *out, int centered) {
     __shared__ FrameLds L;
-    const int env = blockIdx.x;
-    if (env >= a.n) return;
+    if ((int)blockIdx.x >= a.n) return;
+    // heavy-first: the envs whose frame took longest last time (many drawables in the window) are dispatched first
+    const int env = a.wg_order ? (int)a.wg_order[blockIdx.x] : (int)blockIdx.x;
+    const unsigned long long pf_t0 = a.wg_cost ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifdef NPP_RENDER_STAMPS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -705,6 +707,7 @@ __global__ __launch_bounds__(256, NPP_RENDER_OCC) void npp_render_kernel(KernelA
 #endif
     if (wd.h == 0 || wd.w == 0) {        // the window lies outside the canvas (axis swap with player_x > 642): all padding
         for (int q = threadIdx.x; q < DW_PER_ROW * FH; q += blockDim.x) dst[q] = 0;
+        if (a.wg_cost && threadIdx.x == 0) a.wg_cost[env] = (uint32_t)(__builtin_amdgcn_s_memtime() - pf_t0);
         return;
     }
     // One wavefront builds the draw list while the other three stage the level's tile ids (1100 bytes; 64 envs per level keep
@@ -756,6 +759,7 @@ __global__ __launch_bounds__(256, NPP_RENDER_OCC) void npp_render_kernel(KernelA
         v |= __shfl_xor(v, 2, 64);
         if (j == 0) dst[q] = v;
     }
+    if (a.wg_cost && threadIdx.x == 0) a.wg_cost[env] = (uint32_t)(__builtin_amdgcn_s_memtime() - pf_t0);   // wavefront 0's view of the frame
 #ifdef NPP_RENDER_STAMPS
     __syncthreads();
     if (threadIdx.x == bw * 64) {   // diagnostic build only: phase durations (shader clocks, builder wavefront) over the frame's first bytes
