@@ -1808,18 +1808,24 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 
 // LDS_LEVEL is chosen by the host: true when every workgroup's envs play one level that fits the LDS budget
 // (the host knows the env -> level assignment), false otherwise (tables are read through L1/L2).
-// Register budget: the second launch-bound argument is the minimum number of wavefronts per SIMD.  Measured on MI355X
-// (profiles/r02_occupancy_ab.txt, tools/occupancy_ab.py): capping the kernel at 256 unified registers (2 wavefronts per SIMD,
-// all 2048 wavefronts of an 8192-env launch resident at once) changes NOTHING at 8192 envs (160.7 vs 160.5 us: the launch
-// lasts as long as its slowest env's serial chain, not as long as its wavefronts queue) and LOSES at the batch sizes where
-// throughput matters (32 768 envs, G = 8: 699 vs 404 us; 65 536 envs, G = 4: 810 vs 555 us) because the G <= 8
-// instantiations then spill ~360 VGPRs to scratch.  So the allocator keeps its free hand (1 wavefront per SIMD, AGPRs as
-// spill space); -DNPP_MIN_WAVES=2 rebuilds the capped variant for A/B runs.
+// Register budget: the second launch-bound argument is the minimum number of wavefronts per SIMD.  Measured on MI355X:
+// * mid-round 2 (profiles/r02_occupancy_ab.txt, tools/occupancy_ab.py), before the heavy-first workgroup order: capping the kernel at
+//   256 unified registers (2 wavefronts per SIMD, all 2048 wavefronts of an 8192-env launch resident at once) changed NOTHING at 8192
+//   envs on the straggler-heavy first 600 steps (160.7 vs 160.5 us) and LOST at the batch sizes where throughput matters (32 768 envs,
+//   G = 8: 699 vs 404 us; 65 536 envs, G = 8 / 4: 810 vs 555 us) because the G <= 8 instantiations then spill ~360 VGPRs to scratch;
+// * end of round 2, with the heavy-first order and in the bench's steady state: the G = 16 kernels capped at 2 wavefronts per SIMD
+//   (196 VGPRs spilled outside the depenetration loop, 648 B of scratch per lane) take the headline from 68.2 to 75.5 M env-steps/s
+//   (launch mean 120 -> 108 us, p50 111 -> 96: no second residency round any more; p95 221 -> 246: the slowest chain shares its SIMD for
+//   the first ~30 us) and the mine levels from 80.0 to 97.7 M (102 -> 84 us), and cost the door levels 5 % (241 -> 253 us: every launch
+//   there is one long chain).
+// So: G >= 16 (up to 16 384 envs) is built for 2 wavefronts per SIMD, G <= 8 and the zoo kernels keep the allocator's free hand
+// (1 wavefront per SIMD, AGPRs as spill space).  -DNPP_MIN_WAVES=1 rebuilds the uncapped G >= 16 kernels for A/B runs.
 #ifndef NPP_MIN_WAVES
-#define NPP_MIN_WAVES 1
+#define NPP_MIN_WAVES 2
 #endif
+
 template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
-__global__ __launch_bounds__(256, (ZOO ? 1 : NPP_MIN_WAVES)) void npp_step_kernel(KernelArgs a) {
+__global__ __launch_bounds__(256, ((ZOO || G < 16) ? 1 : NPP_MIN_WAVES)) void npp_step_kernel(KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     run<G, LDS_LEVEL, ZOO, MANY>(a, smem);
 }

@@ -18,11 +18,17 @@ def main():
     import torch
     from nclone_amd import _native as nat
 
-    out = os.path.join(ROOT, "nclone_amd", "libnpp_amd_stamps.so")
+    # built in the build container (hipcc cross-compiles; ~4 min for the single translation unit) and shipped to the GPU box in build_ab/
+    out = os.path.join(ROOT, "build_ab", "libnpp_stamps.so")
     csrc = os.path.join(ROOT, "nclone_amd", "csrc")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                           "-DNPP_STAMPS", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-o", out] +
-                          [os.path.join(csrc, f) for f in ("npp_kernels.hip", "npp_render.hip", "npp_capi.cpp", "npp_level.cpp")])
+    if not os.path.isfile(out) or "--build" in sys.argv:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-DNPP_STAMPS", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-o", out] +
+                              [os.path.join(csrc, f) for f in ("npp_kernels.hip", "npp_render.hip", "npp_reach_kernel.hip", "npp_capi.cpp",
+                                                               "npp_level.cpp", "npp_reach.cpp")])
+        if "--build" in sys.argv:
+            return
     nat.LIB_PATH = out
     from nclone_amd.engine import NppBatch
     from nclone_amd import levels as level_sets
@@ -36,7 +42,7 @@ def main():
     rng = np.random.default_rng(0)
     K, W = 100, 100
     acts = torch.from_numpy(rng.integers(0, 6, size=(K + W, n)).astype(np.uint8)).cuda()
-    for g in [int(x) for x in (sys.argv[1:] or ["64", "16"])]:
+    for g in [int(x) for x in ([v for v in sys.argv[1:] if not v.startswith("-")] or ["64", "16"])]:
         b = NppBatch(n, autoreset=True)
         b.load_levels(levels)
         b.set_launch_geometry(g, 1)
