@@ -20,7 +20,8 @@ Workloads:
   zoo      the 26 entity-zoo maps
 
 Before --warmup is honoured a fixed pre-roll of PREROLL_STEPS launches runs (reported as preroll_steps): episodes
-desynchronise and clocks ramp, so the figure does not depend on the caller's warm-up.  Every launch of the timed region
+desynchronise, clocks ramp and npp_step's build-variant autotuner (256 + 9 x 48 launches) reaches its decision, so the figure
+does not depend on the caller's warm-up.  Every launch of the timed region
 is bracketed by HIP events on the launch stream: mean / p50 / p95 / max are reported, together with the levels that own
 the slowest 5 % of the launches (the env with the most depenetration iterations in that launch, npp_step_out.d_work).
 
@@ -42,7 +43,7 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 8192
 FRAME_SKIP = 4
-PREROLL_STEPS = 300
+PREROLL_STEPS = 1000
 # algorithmic HBM bytes per env-step for the game_state-only observation
 # (state read 160 + state write 160 + action 1 + outputs 201)
 ALGO_BYTES_PER_ENV_STEP = 522
@@ -283,6 +284,10 @@ def main():
         one(k)
     dt, step_us, render_us = timed(P + W)
     done_frac = float((b.flags & 3).ne(0).float().mean().item())
+    # build variant of the G = 16 step kernels picked by npp_step's autotuner during the pre-roll (include/npp_amd.h: npp_set_step_variant)
+    sv = b.step_variant()
+    step_variant = {"variant": int(sv[0]), "tuned": bool(sv[1]),
+                    "meaning": "0: 2 wavefronts/SIMD, 2 candidate slots; 1: 2 wavefronts/SIMD, 1 slot; 2: 1 wavefront/SIMD, 2 slots"}
 
     # which levels own the slow launches: the env with the most depenetration iterations in each of the slowest 5 %
     lt = np.asarray(step_us)
@@ -413,6 +418,7 @@ def main():
                 "terminated_frac_last_step": done_frac,
             },
             "launch_us": pl,
+            "step_variant": step_variant,
             "stragglers": stragglers,
             "roofline": {
                 "bound": "hbm",

@@ -207,6 +207,17 @@ int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int m
                                uint32_t *unsupported_mask);
 int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out);
 
+/* Build variant of the step kernel (a speed knob like npp_set_launch_geometry; results are bit-identical for every variant; no
+ * counterpart in the reference).  The 16-lanes-per-env kernels of levels without moving entities exist in three builds -- 0: two
+ * wavefronts per SIMD, two candidate slots per lane; 1: two wavefronts per SIMD, one slot (fastest on sparse geometry, slow where
+ * creases gather more than 16 segments); 2: one wavefront per SIMD, two slots (fastest single chain) -- and npp_step times them
+ * against each other on the handle's own workload (HIP events, no synchronisation) after every npp_load_levels /
+ * npp_assign_levels and keeps the fastest.  variant = -1 (default) selects that autotuner, 0..2 pin a build.
+ * npp_get_step_variant: *variant = the build npp_step currently launches, *tuned = 1 once the autotuner has decided (or a build is
+ * pinned). */
+int npp_set_step_variant(npp_handle h, int variant);
+int npp_get_step_variant(npp_handle h, int *variant, int *tuned);
+
 /* Host-only: the per-level reachability tables of one level, stage by stage (CPU tests compare them with the reference's,
  * tests/golden/reach.npz).  Node id = i * 46 + j for the sub-node at tile-data pixel (6 + 12 i, 6 + 12 j), 84 x 46 = 3864 ids.
  * info i32[16]: supported, len(adjacency), goal node of exit_switch_0 / exit_door_0 in the level cache, the two goal nodes

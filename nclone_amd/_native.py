@@ -26,7 +26,7 @@ EXPORTS = [
     "npp_create", "npp_destroy", "npp_last_error", "npp_set_stream", "npp_sync", "npp_load_levels",
     "npp_assign_levels", "npp_reset", "npp_set_truncation_limit", "npp_step", "npp_tick", "npp_observe",
     "npp_render_player_frame", "npp_dump_state", "npp_dump_entities", "npp_dump_level_segments",
-    "npp_compile_level_segments", "npp_compile_level_entities", "npp_num_envs", "npp_num_levels",
+    "npp_compile_level_segments", "npp_compile_level_entities", "npp_set_step_variant", "npp_get_step_variant", "npp_num_envs", "npp_num_levels",
     "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many", "npp_render_frame", "npp_plan_zoo_block", "npp_reset_ex",
     "npp_reachability", "npp_reach_compile", "npp_reach_features_host",
 ]
@@ -93,6 +93,8 @@ def lib():
     ]
     L.npp_compile_level_entities.argtypes = [C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
     L.npp_set_launch_geometry.argtypes = [H, C.c_int, C.c_int]
+    L.npp_set_step_variant.argtypes = [H, C.c_int]
+    L.npp_get_step_variant.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.npp_get_launch_geometry.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.npp_entity_checksum.argtypes = [H, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.npp_compile_level_zoo.argtypes = [C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]

@@ -53,6 +53,15 @@ struct npp_handle_s {
     uint32_t *d_wg_order = nullptr, *d_wg_cost = nullptr;   // npp_step: heavy-first workgroup order and the per-block cost behind it
     int wg_blocks = 0;
     long step_launches = 0;
+    // autotuner of the step-kernel build variant (npp_kernels.hip: VariantK): windows of TUNE_WINDOW launches per variant, timed
+    // with one pair of HIP events each (never synchronised: the decision is taken once the last event has completed)
+    int variant_pin = -1;            // -1 = autotune
+    int variant = 0;                 // what npp_step launches now
+    int tune_state = 0;              // 0 = warm-up, 1 .. TUNE_ROUNDS * 3 = measuring windows, > that = waiting for events / decided
+    int tune_count = 0;              // launches inside the current state
+    bool tuned = false;
+    hipEvent_t tune_ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // window boundaries
+    long tune_since = 0;             // launches since the last decision
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
     unsigned char *d_rblob = nullptr;
@@ -160,6 +169,9 @@ void plan_geometry(npp_handle h) {
     }
     h->geo_g = g;
     h->geo_wpb = wpb;
+    // a new plan (level set, assignment, overrides, geometry) restarts npp_step's variant autotuner
+    h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
+    h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
     // can every workgroup stage ONE level?  (the host owns the env -> level assignment)
     int epb = (64 / g) * wpb;
     int ok = !h->hdrs.empty();
@@ -197,6 +209,7 @@ KernelArgs base_args(npp_handle h) {
     a.zoo_doors = h->zoo_doors;
     a.zoo_movers = h->zoo_movers;
     a.zoo_active = h->zoo_active;
+    a.variant = (h->geo_g == 16 && !h->zoo_active) ? h->variant : 0;   // npp_step's autotuner (or the pinned build)
     return a;
 }
 
@@ -349,6 +362,8 @@ int npp_destroy(npp_handle h) {
     hipFree(h->d_mask); hipFree(h->d_blob); hipFree(h->d_hdr); hipFree(h->d_sc_cache); hipFree(h->d_canvas);
     hipFree(h->d_gv_h); hipFree(h->d_gv_v); hipFree(h->d_gv_p);
     hipFree(h->d_gv_x); hipFree(h->d_gv_order); hipFree(h->d_gv_cost); hipFree(h->d_wg_order); hipFree(h->d_wg_cost); hipFree(h->d_pf_order); hipFree(h->d_pf_cost);
+    for (auto &e : h->tune_ev)
+        if (e) hipEventDestroy(e);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -638,6 +653,74 @@ int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
     return NPP_OK;
 }
 
+#ifndef NPP_STEP_FOLD
+#define NPP_STEP_FOLD 0
+#endif
+namespace {
+// 256 launches of warm-up (episodes desynchronise: right after a reset every env sits at its spawn and the launches are dominated by
+// the levels with a crease under the spawn, which favours variant 2 -- a first cut that tuned on launches 48 .. 288 picked it for the
+// mixed set and lost 10 %), then 9 interleaved windows of 48 launches; the decision is re-examined every 16 384 launches
+constexpr int TUNE_WARM = 256, TUNE_WINDOW = 48, TUNE_ROUNDS = 3, TUNE_AGAIN = 16384;
+// restart the tuner (new level set / assignment / geometry): the warm-up also lets the heavy-first order settle
+void tune_reset(npp_handle h) {
+    h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
+    h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
+}
+// called by npp_step before every launch; returns the variant to launch and records the window boundaries on the stream
+int tune_next(npp_handle h) {
+    if (h->variant_pin >= 0) return h->variant_pin;
+    if (h->geo_g != 16 || h->zoo_active) return 0;   // only the plain G = 16 kernels have variants
+    if (h->tuned) {
+        if (++h->tune_since < TUNE_AGAIN) return h->variant;
+        h->tuned = false; h->tune_state = 0; h->tune_count = TUNE_WARM; h->tune_since = 0;   // measure again, no warm-up needed
+    }
+    const int n_win = 3 * TUNE_ROUNDS;
+    if (h->tune_state == 0) {   // warm-up on variant 0
+        if (++h->tune_count <= TUNE_WARM) return h->variant;
+        for (auto &e : h->tune_ev)
+            if (!e && hipEventCreate(&e) != hipSuccess) { h->tuned = true; h->variant = 0; return 0; }   // no events: stay on 0
+        hipEventRecord(h->tune_ev[0], h->stream);
+        h->tune_state = 1; h->tune_count = 0;
+    }
+    if (h->tune_state <= n_win) {   // window w measures variant (w - 1) % 3
+        if (h->tune_count == TUNE_WINDOW) {
+            hipEventRecord(h->tune_ev[h->tune_state], h->stream);
+            h->tune_state++; h->tune_count = 0;
+        }
+        if (h->tune_state <= n_win) { h->tune_count++; return (h->tune_state - 1) % 3; }
+    }
+    // all windows recorded: decide as soon as the last boundary has been reached by the GPU (no waiting)
+    if (hipEventQuery(h->tune_ev[n_win]) == hipSuccess) {
+        float t[3] = {0.f, 0.f, 0.f};
+        bool ok = true;
+        for (int w = 1; w <= n_win; w++) {
+            float ms = 0.f;
+            ok = ok && hipEventElapsedTime(&ms, h->tune_ev[w - 1], h->tune_ev[w]) == hipSuccess;
+            t[(w - 1) % 3] += ms;
+        }
+        int best = 0;
+        if (ok) for (int v = 1; v < 3; v++) if (t[v] < t[best]) best = v;
+        h->variant = best; h->tuned = true; h->tune_since = 0;
+        return best;
+    }
+    return h->variant;
+}
+}  // namespace
+
+int npp_set_step_variant(npp_handle h, int variant) {
+    if (!h || variant < -1 || variant > 2) return fail(h, NPP_ERR_INVALID, "npp_set_step_variant: variant must be -1 (autotune) or 0..2");
+    h->variant_pin = variant;
+    tune_reset(h);
+    return NPP_OK;
+}
+
+int npp_get_step_variant(npp_handle h, int *variant, int *tuned) {
+    if (!h) return NPP_ERR_INVALID;
+    if (variant) *variant = (h->geo_g == 16 && !h->zoo_active) ? h->variant : 0;
+    if (tuned) *tuned = (h->tuned || h->variant_pin >= 0 || h->geo_g != 16 || h->zoo_active) ? 1 : 0;
+    return NPP_OK;
+}
+
 int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_step_out *out) {
     if (!h || !d_actions || frame_skip <= 0) return fail(h, NPP_ERR_INVALID, "npp_step: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_step: no levels loaded");
@@ -656,9 +739,10 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
             h->wg_blocks = 0;
         }
         const bool fresh = blocks != h->wg_blocks;
+        if (fresh) tune_reset(h);
         if (fresh || h->step_launches % 16 == 0) {
             if (fresh) HIP_TRY(h, hipMemsetAsync(h->d_wg_cost, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
-            HIP_TRY(h, launch_cost_order(h->d_wg_cost, h->d_wg_order, blocks, h->stream));
+            HIP_TRY(h, launch_cost_order(h->d_wg_cost, h->d_wg_order, blocks, NPP_STEP_FOLD, h->stream));
             HIP_TRY(h, hipMemsetAsync(h->d_wg_cost, 0, (size_t)blocks * sizeof(uint32_t), h->stream));   // costs are maxima over the next 16 launches
             h->wg_blocks = blocks;
         }
@@ -666,6 +750,7 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
         a.wg_order = h->d_wg_order;
         a.wg_cost = h->d_wg_cost;
     }
+    a.variant = tune_next(h);
     HIP_TRY(h, launch_step(a, h->stream));
     return NPP_OK;
 }
@@ -724,7 +809,7 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
             HIP_TRY(h, hipMemsetAsync(h->d_pf_cost, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
             h->pf_launches = 0;
         }
-        if (h->pf_launches % 8 < 2) HIP_TRY(h, launch_cost_order(h->d_pf_cost, h->d_pf_order, h->n, h->stream));
+        if (h->pf_launches % 8 < 2) HIP_TRY(h, launch_cost_order(h->d_pf_cost, h->d_pf_order, h->n, 0, h->stream));
         h->pf_launches++;
         a.wg_order = h->d_pf_order;
         a.wg_cost = h->d_pf_cost;

@@ -455,6 +455,16 @@ DEV bool cell_passes(uint32_t cb, int xc, int yc, double qx0, double qy0, double
 // All filters are evaluated in doubles on exact quantities (multiples of 12 px), so no integer cell arithmetic is
 // needed on the fast path.
 template <int G> struct KSlots { static constexpr int value = G >= 32 ? 1 : (G >= 16 ? 2 : 4); };
+// Build variants of the G = 16 plain (non-zoo) step kernels, chosen per handle by npp_step's autotuner (npp_capi.cpp) because no
+// one of them wins everywhere (8192 envs, MI355X, end of round 2):
+//   V = 0  2 wavefronts per SIMD, 2 candidate slots per lane   headline 75.9 M env-steps/s, door levels 32.3 M, mine levels 97.6 M
+//   V = 1  2 wavefronts per SIMD, 1 candidate slot per lane    headline 83.0 M (63 instead of 196 spilled VGPRs), mine levels 100.9 M, but
+//                                                               door levels 25.5 M: their creases gather more than 16 segments and
+//                                                               every iteration then takes the LDS fallback
+//   V = 2  1 wavefront per SIMD (no register cap), 2 slots      headline 68.3 M, door levels 34.0 M (one long chain per launch: the
+//                                                               fastest single chain wins)
+// All variants give the same bits (tests/test_gpu_parity.py).  Other G and the zoo kernels exist as V = 0 only.
+template <int G, bool ZOO, int V> struct VariantK { static constexpr int value = (G == 16 && !ZOO && V == 1) ? 1 : KSlots<G>::value; };
 
 DEV double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -1294,9 +1304,9 @@ DEV void ninja_think(Nj &n, const double *lp) {
 }
 
 // Simulator.tick (nsim.py:221-292)
-template <int G, bool ZOO>
+template <int G, bool ZOO, int V>
 DEV void sim_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb, int hor, int jump, int n_ent STAMP_ARG) {
-    constexpr int K = KSlots<G>::value;
+    constexpr int K = VariantK<G, ZOO, V>::value;
     STAMP_INIT;
     n.frame += 1;
     n.hor = hor;
@@ -1565,7 +1575,7 @@ DEV void episode_reset(const KernelArgs &a, const LevelHdr &H, Lv &lv, Zoo &z, N
 }
 
 // G lanes per env; EPW = 64 / G envs per wavefront; blockDim.x / 64 wavefronts per workgroup
-template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
+template <int G, bool LDS_LEVEL, bool ZOO, bool MANY, int V>
 DEV void run(const KernelArgs &a, unsigned char *smem) {
     constexpr int EPW = WAVE / G;
     const int tid = threadIdx.x;
@@ -1707,7 +1717,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
                     jump = b & 1;
                 }
                 if (live) {
-                    sim_tick<G, ZOO>(lv, z, r, n, eb, hor, jump, (int)H.n_ent STAMP_PASS);
+                    sim_tick<G, ZOO, V>(lv, z, r, n, eb, hor, jump, (int)H.n_ent STAMP_PASS);
                     executed++;
                     if (gym && (n.state == 8 || n.state == 6 || n.state == 7)) live = false;
                 }
@@ -1824,10 +1834,10 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 #define NPP_MIN_WAVES 2
 #endif
 
-template <int G, bool LDS_LEVEL, bool ZOO, bool MANY>
-__global__ __launch_bounds__(256, ((ZOO || G < 16) ? 1 : NPP_MIN_WAVES)) void npp_step_kernel(KernelArgs a) {
+template <int G, bool LDS_LEVEL, bool ZOO, bool MANY, int V>
+__global__ __launch_bounds__(256, ((ZOO || G < 16 || V == 2) ? 1 : NPP_MIN_WAVES)) void npp_step_kernel(KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    run<G, LDS_LEVEL, ZOO, MANY>(a, smem);
+    run<G, LDS_LEVEL, ZOO, MANY, V>(a, smem);
 }
 
 // Simulator.reset / fast_reset (nsim.py:62-140) for masked envs
@@ -1898,8 +1908,20 @@ hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
     const dim3 grid(blocks), block(WAVE * wpb);
     // zoo levels: LDS also holds the per-env zoo blocks
     const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb, Z ? a.zoo_words : 0);
-    if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, Z, M>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((npp_step_kernel<G, false, Z, M>), grid, block, lds, s, a);
+    if constexpr (G == 16 && !Z) {
+        if (a.variant == 1) {
+            if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, Z, M, 1>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((npp_step_kernel<G, false, Z, M, 1>), grid, block, lds, s, a);
+            return hipGetLastError();
+        }
+        if (a.variant == 2) {
+            if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, Z, M, 2>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((npp_step_kernel<G, false, Z, M, 2>), grid, block, lds, s, a);
+            return hipGetLastError();
+        }
+    }
+    if (a.lds_level) hipLaunchKernelGGL((npp_step_kernel<G, true, Z, M, 0>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((npp_step_kernel<G, false, Z, M, 0>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 

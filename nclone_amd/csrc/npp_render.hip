@@ -1464,7 +1464,7 @@ __device__ inline int gv_cost_bin(uint32_t c) {
     const int msb = 31 - __builtin_clz(c);                 // 4 .. 31
     return (msb - 4) * 4 + (int)((c >> (msb - 2)) & 3u) + 1;   // 1 .. 112
 }
-__global__ __launch_bounds__(1024) void npp_gv_order_kernel(const uint32_t *cost, uint32_t *order, int n) {
+__global__ __launch_bounds__(1024) void npp_gv_order_kernel(const uint32_t *cost, uint32_t *order, int n, int fold) {
     __shared__ int hist[128];
     __shared__ int base[128];
     if (threadIdx.x < 128) hist[threadIdx.x] = 0;
@@ -1476,7 +1476,16 @@ __global__ __launch_bounds__(1024) void npp_gv_order_kernel(const uint32_t *cost
         for (int b = 127; b >= 0; b--) { base[b] = acc; acc += hist[b]; }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += blockDim.x) order[atomicAdd(&base[gv_cost_bin(cost[e])], 1)] = (uint32_t)e;
+    // `fold` > 0 (npp_step, two workgroups per CU): positions fold .. 2 fold - 1 are filled backwards, so that if the dispatcher gives
+    // workgroup fold + k the second slot of workgroup k's CU the heaviest workgroups share their CU with the lightest ones
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        int pos = atomicAdd(&base[gv_cost_bin(cost[e])], 1);
+        if (fold > 0 && pos >= fold && pos < 2 * fold) {
+            const int hi = (2 * fold < n ? 2 * fold : n) - 1;
+            pos = fold + (hi - pos);
+        }
+        order[pos] = (uint32_t)e;
+    }
 }
 
 // The cell pass of the envs that exported it: GV_XWAVES wavefronts per env; wavefront j stages the env's boxes / patches from its
@@ -1617,7 +1626,7 @@ hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_
 #ifndef NPP_GV_SPLIT
     xscr = nullptr;   // shipped: the whole cell pass inside the first kernel (the split variant is an A/B build, see above)
 #endif
-    if (order && reorder) hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, a.n);
+    if (order && reorder) hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, a.n, 0);
     hipLaunchKernelGGL(npp_global_view_kernel, dim3((a.n + GV_WPB - 1) / GV_WPB), dim3(64 * GV_WPB), GV_WPB * gv_lds_bytes(cap), s, a, cap, gv_p, gv_h,
                        gv_v, d_out, xscr, order, cost);
     if (xscr)
@@ -1625,8 +1634,8 @@ hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_
     return hipGetLastError();
 }
 
-hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, hipStream_t s) {
-    hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, n);
+hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, int fold, hipStream_t s) {
+    hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, n, fold);
     return hipGetLastError();
 }
 

@@ -230,6 +230,16 @@ class NppBatch:
     def set_launch_geometry(self, lanes_per_env=0, waves_per_block=0):
         nat.check(self.h, self.lib.npp_set_launch_geometry(self.h, int(lanes_per_env), int(waves_per_block)))
 
+    def set_step_variant(self, variant=-1):
+        """Build variant of the step kernel: -1 = autotune on this handle's workload (default), 0..2 pin one (same bits either way)."""
+        nat.check(self.h, self.lib.npp_set_step_variant(self.h, int(variant)))
+
+    def step_variant(self):
+        """(variant npp_step launches now, True once the autotuner has decided or a variant is pinned)"""
+        v, t = C.c_int(0), C.c_int(0)
+        nat.check(self.h, self.lib.npp_get_step_variant(self.h, C.byref(v), C.byref(t)))
+        return v.value, bool(t.value)
+
     def launch_geometry(self):
         g, w = C.c_int(0), C.c_int(0)
         nat.check(self.h, self.lib.npp_get_launch_geometry(self.h, C.byref(g), C.byref(w)))

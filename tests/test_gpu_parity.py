@@ -216,11 +216,15 @@ def test_launch_geometries_bit_identical(golden):
     rng = np.random.default_rng(11)
     acts = torch.from_numpy(rng.integers(0, 6, size=(steps, n)).astype(np.uint8)).cuda()
     ref = None
-    for g, wpb in [(1, 1), (1, 4), (2, 2), (4, 4), (8, 1), (8, 4), (16, 4), (32, 2), (64, 4)]:
+    # the three build variants of the G = 16 kernels (register cap / candidate slots; npp_set_step_variant) are geometries too
+    for g, wpb, var in [(1, 1, 0), (1, 4, 0), (2, 2, 0), (4, 4, 0), (8, 1, 0), (8, 4, 0), (16, 4, 0), (16, 4, 1), (16, 4, 2), (16, 2, 1),
+                        (32, 2, 0), (64, 4, 0)]:
         b = _batch(n, autoreset=True)
         b.load_levels(levels)
         b.set_launch_geometry(g, wpb)
+        b.set_step_variant(var)
         assert b.launch_geometry()[0] == g
+        assert b.step_variant() == (var if g == 16 else 0, True)
         b.assign_levels(np.arange(n) % len(levels))
         tot_flags = np.zeros(n, dtype=np.int64)
         for s in range(steps):
@@ -235,7 +239,7 @@ def test_launch_geometries_bit_identical(golden):
             ref = cur
         else:
             for x, y in zip(ref, cur):
-                assert np.array_equal(x, y), (g, wpb)
+                assert np.array_equal(x, y), (g, wpb, var)
 
 
 def test_spatial_context_matches_reference(golden, oracle_mod):

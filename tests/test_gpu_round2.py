@@ -357,3 +357,32 @@ def test_fast_reset_autoreset_vs_oracle(oracle_mod):
     bs = run(False)
     cs2 = bs.entity_checksum()
     assert not np.array_equal(cs[lvl < 10], cs2[lvl < 10])
+
+
+def test_step_variant_autotuner_decides_and_keeps_the_bits():
+    """npp_step's autotuner (HIP-event windows over the three G = 16 build variants) reaches a decision without any synchronisation on
+    the caller's side, and a run that goes through the tuning windows ends in the same state as a run pinned to variant 0."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import curriculum0_levels
+
+    levels, _ = curriculum0_levels()
+    n = 2048
+    lvl = (np.arange(n) // 64) % len(levels)
+    acts = torch.from_numpy(np.random.default_rng(5).integers(0, 6, size=(720, n)).astype(np.uint8)).cuda()
+    outs = []
+    for pin in (-1, 0):
+        b = NppBatch(n, autoreset=True)
+        b.load_levels(levels)
+        b.assign_levels(lvl)
+        b.set_launch_geometry(16, 4)
+        b.set_step_variant(pin)
+        for s in range(720):
+            b.step(acts[s])
+        torch.cuda.synchronize()
+        b.step(acts[0])   # one more launch after the last window's events have completed: the tuner decides here
+        v, tuned = b.step_variant()
+        assert tuned and v in (0, 1, 2), (pin, v, tuned)
+        outs.append(b.dump_state() + (b.game_state.cpu().numpy(),))
+        b.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
