@@ -60,6 +60,8 @@ def committed_traffic(kind="step"):
 
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        if ("render" in os.path.basename(f)) != (kind != "step"):
+            continue   # <round>_summary.json: the headline workload's step kernel; <round>_render_summary.json: the config-3 run
         try:
             j = json.load(open(f))
             t = j.get("traffic" if kind == "step" else "render_traffic", {}).get("hbm_bytes_per_launch")

@@ -17,12 +17,26 @@ def find(d, pat):
     return r[0] if r else None
 
 
-def counter_means(path, kernel="npp_step_kernel"):
+def counter_means(path, kernel="npp_step_kernel", last=None):
+    """Mean counter value per dispatch of `kernel`; `last` = only the last N dispatches (the bench's timed region: the launches
+    before it are the pre-roll, during which npp_step's autotuner rotates through the kernel's build variants)."""
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    names = collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
         if kernel in r["Kernel_Name"]:
-            agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    return {c: {"dispatches": len(d), "mean_per_dispatch": sum(d.values()) / len(d)} for c, d in agg.items()}
+            agg[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+            names[int(r["Dispatch_Id"])].add(r["Kernel_Name"])
+    out = {}
+    for c, d in agg.items():
+        ids = sorted(d)
+        if last:
+            ids = ids[-last:]
+        out[c] = {"dispatches": len(ids), "mean_per_dispatch": sum(d[i] for i in ids) / len(ids),
+                  "kernels": sorted({k for i in ids for k in names[i]})}
+    return out
+
+
+TIMED = 300   # tools/profile_round.sh runs bench.py --steps 300
 
 
 def main():
@@ -56,6 +70,7 @@ def main():
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
         out["step_kernel"]["timed_region_avg_ns"] = sum(d) / len(d)
         out["step_kernel"]["timed_region_launches"] = len(d)
+        out["step_kernel"]["timed_region_kernel"] = last[-1]["Kernel_Name"]
         # launch descriptor as the kernel trace reports it (arch VGPRs and AGPRs are separate columns; LDS is the dynamic +
         # static allocation of the dispatch; scratch in bytes per lane)
         for col, name in (("Grid_Size_X", "grid_size_x"), ("Workgroup_Size_X", "workgroup_size_x"), ("VGPR_Count", "arch_vgpr"),
@@ -73,7 +88,7 @@ def main():
     for name in ("fetch", "write"):
         cc = find(os.path.join(src, name), "*counter_collection.csv")
         if cc:
-            traffic.update(counter_means(cc))
+            traffic.update(counter_means(cc, last=TIMED))
     if traffic:
         # FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B (hbm_bytes = value * 1024); on gfx950
         # FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams (x2 correction).  This kernel's reads
@@ -92,7 +107,7 @@ def main():
     for name in ("fetch", "write"):
         cc = find(os.path.join(src, name), "*counter_collection.csv")
         if cc:
-            rtraffic.update(counter_means(cc, "npp_render_kernel"))
+            rtraffic.update(counter_means(cc, "npp_render_kernel", last=TIMED))
     if rtraffic:
         # the render kernel reads with dword loads and writes with dword stores: FETCH_SIZE recorded raw and x2 (the x2
         # correction is calibrated for 16 B / lane streams only); WRITE_SIZE is exact for coalesced stores
@@ -106,8 +121,8 @@ def main():
             out["render_traffic"]["hbm_bytes_per_launch"] = fs * 2048 + ws * 1024
     sq = find(os.path.join(src, "sq"), "*counter_collection.csv")
     if sq:
-        out["sq"] = counter_means(sq)
-        rs = counter_means(sq, "npp_render_kernel")
+        out["sq"] = counter_means(sq, last=TIMED)
+        rs = counter_means(sq, "npp_render_kernel", last=TIMED)
         if rs:
             out["sq_render"] = rs
     bl = os.path.join(src, "bench_line.json")
