@@ -200,6 +200,41 @@ def test_step_many_equals_single_steps():
     assert int((torch.stack(fl) & 11).ne(0).sum()) > 50      # episodes did end (and restart) inside the sequences
 
 
+def test_step_many_under_every_build_variant():
+    """npp_step_many on plain levels under each of the three build variants of the G = 16 kernels (npp_set_step_variant) against single
+    steps of variant 0: same final state and per-step flags (the MANY instantiations exist per variant too)."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import curriculum0_levels, mine_levels
+
+    levels = curriculum0_levels()[0][26:32] + mine_levels()[0][:4]
+    n = 64 * len(levels)
+    lvl = np.arange(n) // 64
+    K = 40
+    acts = torch.from_numpy(np.random.default_rng(78).integers(0, 6, size=(K, n)).astype(np.uint8)).cuda()
+    ref = NppBatch(n, autoreset=True)
+    ref.load_levels(levels)
+    ref.assign_levels(lvl)
+    ref.set_launch_geometry(16, 4)
+    ref.set_step_variant(0)
+    fl = []
+    for s in range(K):
+        ref.step(acts[s], want_terminal=False)
+        fl.append(ref.flags.clone())
+    f_ref, i_ref = ref.dump_state()
+    for var in (0, 1, 2):
+        b = NppBatch(n, autoreset=True)
+        b.load_levels(levels)
+        b.assign_levels(lvl)
+        b.set_launch_geometry(16, 4)
+        b.set_step_variant(var)
+        assert b.step_variant() == (var, True)
+        flags, _, _ = b.step_many(acts)
+        f, i = b.dump_state()
+        assert np.array_equal(f, f_ref) and np.array_equal(i, i_ref), var
+        assert torch.equal(flags, torch.stack(fl)), var
+        b.close()
+
+
 def test_long_horizon_soak(oracle_mod):
     """2 600 steps (10 400 ticks: past the 10 000-frame truncation) of 2 048 envs on plain, mine and zoo levels with auto-reset;
     every 43rd env is replayed on the oracle twin (same truncation rule) and must end in the same bits -- thousands of
