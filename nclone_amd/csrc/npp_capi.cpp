@@ -671,7 +671,8 @@ int tune_next(npp_handle h) {
     if (h->variant_pin >= 0) return h->variant_pin;
     if (h->geo_g != 16 || h->zoo_active) return 0;   // only the plain G = 16 kernels have variants
     if (h->tuned) {
-        if (++h->tune_since < TUNE_AGAIN) return h->variant;
+        static const long again = [] { const char *ev = std::getenv("NPP_TUNE_AGAIN"); return ev ? std::atol(ev) : (long)TUNE_AGAIN; }();   // tests shorten it
+        if (++h->tune_since < again) return h->variant;
         h->tuned = false; h->tune_state = 0; h->tune_count = TUNE_WARM; h->tune_since = 0;   // measure again, no warm-up needed
     }
     const int n_win = 3 * TUNE_ROUNDS;

@@ -2,6 +2,7 @@
 scalars, single-block host staging, device guard, npp_reset_ex), the zoo-block regression of the round-1 fault, snapshot /
 restore together with repositioned entities, and the asynchronous vector env."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -357,6 +358,44 @@ def test_fast_reset_autoreset_vs_oracle(oracle_mod):
     bs = run(False)
     cs2 = bs.entity_checksum()
     assert not np.array_equal(cs[lvl < 10], cs2[lvl < 10])
+
+
+def test_step_variant_autotuner_reexamines_its_decision():
+    """The tuner measures again after NPP_TUNE_AGAIN launches (16 384 by default; shortened here through the environment, in a child
+    process because the library reads it once): two full tuning cycles inside 2000 launches, same final bits as a pinned run."""
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np, torch
+from nclone_amd.engine import NppBatch
+from nclone_amd.levels import curriculum0_levels
+levels, _ = curriculum0_levels()
+n = 1024
+lvl = (np.arange(n) // 64) % len(levels)
+acts = torch.from_numpy(np.random.default_rng(6).integers(0, 6, size=(2000, n)).astype(np.uint8)).cuda()
+outs = []
+for pin in (-1, 0):
+    b = NppBatch(n, autoreset=True)
+    b.load_levels(levels); b.assign_levels(lvl); b.set_launch_geometry(16, 4); b.set_step_variant(pin)
+    seen = set()
+    for s in range(2000):
+        b.step(acts[s])
+        if s % 50 == 0:
+            torch.cuda.synchronize()
+            seen.add(b.step_variant())
+    torch.cuda.synchronize()
+    outs.append(b.dump_state())
+    if pin < 0:
+        assert any(t for _, t in seen) and any(not t for _, t in seen), seen   # both tuning and decided phases were observed
+    b.close()
+assert all(np.array_equal(x, y) for x, y in zip(*outs))
+print("OK")
+'''
+    env = dict(os.environ, NPP_TUNE_AGAIN="300")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_step_variant_autotuner_decides_and_keeps_the_bits():
