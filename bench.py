@@ -433,8 +433,9 @@ def main():
                 "kernel": "npp_step_kernel",
                 "avg_launch_us": launch_us,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                "note": "latency/divergence-bound fp64 scalar chains (about 7k dependent flops per env-step); "
-                        "the HBM fraction is tiny by construction (SURVEY.md 8(d))",
+                "note": "issue-cadence-bound fp64 scalar chains (about 7k dependent flops per env-step; DESIGN.md 4.1): the HBM fraction is "
+                        "tiny by construction (SURVEY.md 8(d)); measured traffic above the algorithmic bytes is register-spill scratch of the "
+                        "2-wavefronts-per-SIMD build variants, a deliberate trade (DESIGN.md 4.1, build variants)",
             },
         }
         if render_us is not None:
