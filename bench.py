@@ -25,6 +25,14 @@ does not depend on the caller's warm-up.  Every launch of the timed region
 is bracketed by HIP events on the launch stream: mean / p50 / p95 / max are reported, together with the levels that own
 the slowest 5 % of the launches (the env with the most depenetration iterations in that launch, npp_step_out.d_work).
 
+Without --workload the line carries every BASELINE config that fits the run (round 3):
+  N = 1:  value = config 2 (c0) and `other_configs` = {config3 (mines + player_frame every step), config4_shard (c3mixed, one GPU's
+          8192 of the 65 536 envs), config5_full_obs (doors, every Dict observation every step)}, --other-steps (200) timed steps
+          each after their own pre-roll, each with its own roofline block(s);
+  N > 1:  value = config 2 on N GPUs (so that N = 1 agrees with the line above) and `config4` = c3mixed on the N GPUs with and
+          without the RCCL all_gather of the packed observation block.
+With --workload X the line is that workload alone, as before.
+
 Weak scaling: each rank (one process per GPU) steps its own envs; there is no data-path collective unless --gather-obs.
 Prints ONE JSON line on rank 0.
 """
@@ -49,6 +57,10 @@ PREROLL_STEPS = 1000
 ALGO_BYTES_PER_ENV_STEP = 522
 # player_frame: 7056 B written + ~0.2 KB of state / level tables read per env
 ALGO_BYTES_PER_FRAME = 7056 + 200
+# global_view: 176 x 100 bytes written per env + the env's state / draw records read (the per-level view comes from L2)
+ALGO_BYTES_PER_GLOBAL_VIEW = 17600 + 300
+# reachability: 38 + 3 floats out, position / key / level in, the env's cache row read or written (npp_reach_kernel.hip)
+ALGO_BYTES_PER_REACH = 340
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -130,17 +142,25 @@ def parse_args(argv=None):
     ap.add_argument("--full-obs", action="store_true",
                     help="config 5: every Dict observation inside the timed region -- spatial_context (in the step kernel), "
                          "switch_states, player_frame, global_view, reachability_features + mine_sdf_features; per-kernel times "
-                         "are reported under obs_kernels (levels whose reachability needs the reference's A* search are dropped)")
-    ap.add_argument("--workload", default="c0", choices=["c0", "mines", "doors", "zoo", "c3mixed"],
-                    help="c0 = config 2 (the headline metric); see the module docstring")
+                         "are reported under obs_kernels")
+    ap.add_argument("--workload", default=None, choices=["c0", "mines", "doors", "zoo", "c3mixed"],
+                    help="time this workload alone (c0 = config 2, the headline metric); default: c0 as `value` plus the other "
+                         "BASELINE configs in their own blocks, see the module docstring")
+    ap.add_argument("--other-steps", type=int, default=200,
+                    help="timed steps of each block of `other_configs` / `config4` (0 = leave them out)")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="seconds after which `bench.py --gpus N` gives up on its rank processes")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks itself")
     return ap.parse_args(argv)
 
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's line.
-    The parent never touches torch.cuda / HIP (and never execs): each child initialises its own GPU."""
+    The parent never touches torch.cuda / HIP (and never execs): each child initialises its own GPU.  All children are polled:
+    the first one that exits non-zero ends the run (the others are terminated, then killed after a grace period) with its exit
+    code, and so does --rank-timeout; the other ranks' stdout is relayed to stderr with a rank prefix, stderr is inherited."""
     import socket
+    import threading
 
     port = args.master_port
     if not port:
@@ -152,15 +172,48 @@ def spawn_ranks(args):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out0)
-    sys.stdout.flush()
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE))
+
+    def relay(r, pipe):
+        for raw in iter(pipe.readline, b""):
+            if r == 0:
+                sys.stdout.write(raw.decode(errors="replace"))
+                sys.stdout.flush()
+            else:
+                sys.stderr.write("[rank %d] %s" % (r, raw.decode(errors="replace")))
+                sys.stderr.flush()
+
+    threads = [threading.Thread(target=relay, args=(r, p.stdout), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    deadline = time.monotonic() + args.rank_timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            sys.stderr.write("bench.py: rank processes still running after %.0f s, giving up\n" % args.rank_timeout)
+            rc = 124
+            break
+        time.sleep(0.2)
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    for t in threads:
+        t.join(timeout=5.0)
     return rc
 
 
@@ -168,6 +221,245 @@ def percentiles(us):
     a = np.sort(np.asarray(us, dtype=np.float64))
     return {"mean": float(a.mean()), "p50": float(a[len(a) // 2]), "p95": float(a[min(len(a) - 1, int(0.95 * len(a)))]),
             "max": float(a[-1]), "min": float(a[0])}
+
+
+DESCS = {
+    "c0": "config 2: %d envs/GPU, curriculum_level=0 (exit+switch only: 78 bc_replays maps + maze:tiny/hills:simple "
+          "seeds 100001-100025 = %d levels x 64 envs), game_state+action_mask+entity_positions obs",
+    "mines": "config 3: %d envs/GPU, curriculum_level=2 (mines: 20 bc_replays maps + 44 generated corridor levels = %d levels x 64 envs)",
+    "c3mixed": "config 4: %d envs/GPU (x n_gpus), curriculum_level=3 mixed map set (%d levels: c0 + mines + 320 generated "
+               "simpler/simple levels) x 64 envs",
+    "doors": "config 5: %d envs/GPU, curriculum_level=4 (locked doors / switches, %d levels x 64 envs)",
+    "zoo": "secondary level set 'zoo': %d envs/GPU on the %d entity-zoo maps x 64 envs",
+}
+
+
+def hbm_roofline(kernel, algo_bytes, n, us, traffic=(None, None), note=None):
+    ach = algo_bytes * n / (us["mean"] * 1e-6) / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic[0],
+         "traffic_source": traffic[1], "kernel": kernel, "avg_launch_us": us["mean"], "algorithmic_bytes_per_launch": algo_bytes * n}
+    if note:
+        r["note"] = note
+    return r
+
+
+STEP_NOTE = ("issue-cadence-bound fp64 scalar chains (about 7k dependent flops per env-step; DESIGN.md 4.1): the HBM fraction is tiny by "
+             "construction (SURVEY.md 8(d)); traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE per launch of the committed profile named in "
+             "traffic_source (a process cannot run PMC passes on itself)")
+
+
+def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gather_obs=False, secondaries=False):
+    """Time K npp_step launches (+ the observation kernels asked for) of one workload after P + W untimed ones.  Returns the
+    block of figures for that workload (rank 0) -- `value` is the whole-job rate over all ranks."""
+    import torch
+
+    from nclone_amd import levels as level_sets
+    from nclone_amd.engine import NppBatch
+
+    args, rank, world, dist, n = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"], ctx["n"]
+    barrier, max_over_ranks = ctx["barrier"], ctx["max_over_ranks"]
+    levels, tags = {"c0": level_sets.curriculum0_levels, "mines": level_sets.mine_levels, "doors": level_sets.door_levels,
+                    "zoo": level_sets.zoo_levels, "c3mixed": level_sets.c3_mixed_levels}[workload]()
+    outputs = ["work"] + (["player_frame"] if player_frame else [])
+    if full_obs:
+        outputs += ["spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features"]
+    b = NppBatch(n, device=ctx["local_rank"], autoreset=True, outputs=outputs)
+    STAGES = (("switch_states", lambda: b.switch_states()), ("player_frame", lambda: b.render_player_frame()),
+              ("global_view", lambda: b.render_global_view()), ("reachability", lambda: b.reachability())) if full_obs else ()
+    b.load_levels(levels)
+    # 64 consecutive envs (one wavefront / workgroup) per level, levels repeated round-robin; with more ranks than one the
+    # global env index decides, so that 8 x 8192 envs cover all 512 levels of the mixed set twice
+    env_level = ((np.arange(n) + rank * n) // 64) % len(levels)
+    b.assign_levels(env_level)
+    rng = np.random.default_rng(rank + (2 if workload == "c3mixed" else 0))
+    total = P + W + K
+    acts = torch.from_numpy(rng.integers(0, 6, size=(total, n)).astype(np.uint8)).cuda()
+    work = torch.zeros((K, n), dtype=torch.int16, device="cuda")
+    stream = b.stream
+    stage_us = {}
+
+    def one(k):
+        b.step(acts[k], FRAME_SKIP, want_terminal=False)
+        if player_frame:
+            b.render_player_frame()
+        for _name, fn in STAGES:
+            fn()
+
+    def timed(k0, gather=None):
+        """K launches from step index k0 on, bracketed by barrier + synchronize; per-launch HIP events on the launch stream."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+        mids = [torch.cuda.Event(enable_timing=True) for _ in range(K)] if player_frame else None
+        sevs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES))] for _ in range(K)]
+        barrier()
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for k in range(K):
+            b.step(acts[k0 + k], FRAME_SKIP, want_terminal=False, work_out=work[k])
+            if mids is not None:
+                mids[k].record(stream)
+                b.render_player_frame()
+            for j, (_name, fn) in enumerate(STAGES):
+                sevs[k][j].record(stream)
+                fn()
+            if gather is not None:
+                gather()
+            evs[k + 1].record(stream)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        if STAGES:
+            step_us = [evs[k].elapsed_time(sevs[k][0]) * 1e3 for k in range(K)]
+            render_us = None
+            for j, (name, _fn) in enumerate(STAGES):
+                stage_us[name] = [sevs[k][j].elapsed_time(sevs[k][j + 1] if j + 1 < len(STAGES) else evs[k + 1]) * 1e3 for k in range(K)]
+        elif mids is None:
+            step_us = [evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
+            render_us = None
+        else:
+            step_us = [evs[k].elapsed_time(mids[k]) * 1e3 for k in range(K)]
+            render_us = [mids[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
+        return dt, step_us, render_us
+
+    for k in range(P + W):
+        one(k)
+    dt, step_us, render_us = timed(P + W)
+    done_frac = float((b.flags & 3).ne(0).float().mean().item())
+    # build variant of the G = 16 step kernels picked by npp_step's autotuner during the pre-roll (include/npp_amd.h: npp_set_step_variant)
+    sv = b.step_variant()
+    step_variant = {"variant": int(sv[0]), "tuned": bool(sv[1]),
+                    "meaning": "0: 2 wavefronts/SIMD, 2 candidate slots; 1: 2 wavefronts/SIMD, 1 slot; 2: 1 wavefront/SIMD, 2 slots"}
+
+    # which levels own the slow launches: the env with the most depenetration iterations in each of the slowest 5 %
+    lt = np.asarray(step_us)
+    slow = np.argsort(lt)[-max(1, K // 20):]
+    wk = work[torch.from_numpy(np.sort(slow)).cuda()].cpu().numpy().astype(np.int64) & 0xffff
+    owners = env_level[np.argmax(wk, axis=1)]
+    ids, cnt = np.unique(owners, return_counts=True)
+    top = np.argsort(-cnt)[:6]
+    stragglers = {"launches": int(len(slow)), "iterations_max_env_mean": float(wk.max(axis=1).mean()),
+                  "iterations_all_envs_mean": float(wk.mean()),
+                  "levels": [{"level_id": int(ids[i]), "tag": tags[int(ids[i])], "launches": int(cnt[i])} for i in top]}
+
+    gather_rep = None
+    if gather_obs and dist is not None:
+        packed = b.out.packed()
+        if args.backend == "nccl":
+            gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device="cuda")
+
+            def gather():
+                dist.all_gather_into_tensor(gathered, packed)
+        else:   # gloo rehearsal: host tensors
+            gathered = torch.empty(world * packed.numel(), dtype=torch.uint8)
+            host = torch.empty(packed.numel(), dtype=torch.uint8)
+
+            def gather():
+                host.copy_(packed)
+                dist.all_gather_into_tensor(gathered, host)
+        for k in range(P, P + W):
+            one(k)
+            gather()
+        gdt, _, _ = timed(P + W, gather)
+        parts = b.out.split_packed(gathered, world)
+        ok = bool(torch.equal(parts["game_state"][rank].to(b.game_state.device), b.game_state))
+        gather_rep = {"value": world * n * K / gdt, "unit": "env-steps/s", "ms_per_step": gdt * 1e3 / K,
+                      "bytes_per_rank_per_step": int(packed.numel()), "collective": "all_gather_into_tensor (1 per step)",
+                      "own_shard_roundtrip_ok": ok,
+                      "fields": "game_state f32[41], entity_positions f32[6], reward f32, frames i16, action_mask i8[6], flags u8"}
+
+    # secondary figure: the asynchronous vector env (nclone_amd.async_env.NppAsyncVecEnvironment's engine): the same envs as S
+    # independent sub-batches, each stepped on its own HIP stream with no cross-stream synchronisation until the end
+    async_rep = None
+    S = args.async_streams
+    if secondaries and S > 1 and world == 1 and n % (S * 64) == 0 and not gather_obs and not player_frame and not full_obs:
+        from nclone_amd.async_env import AsyncBatches
+
+        ab = AsyncBatches(n, S, device=ctx["local_rank"], autoreset=True)
+        ab.load_levels(levels)
+        ab.assign_levels(env_level)
+        torch.cuda.synchronize()
+        views = [acts[:, k * (n // S):(k + 1) * (n // S)].contiguous() for k in range(S)]
+        for t in range(P + W):
+            ab.step_async([v[t] for v in views], FRAME_SKIP)
+        ab.wait()
+        t0 = time.perf_counter()
+        for t in range(P + W, total):
+            ab.step_async([v[t] for v in views], FRAME_SKIP)
+        ab.wait()
+        adt = time.perf_counter() - t0
+        async_rep = {"streams": S, "envs_per_stream": n // S, "value": n * K / adt, "unit": "env-steps/s",
+                     "ms_per_step_all_streams": adt * 1e3 / K,
+                     "note": "same envs, levels and actions as `value`, stepped as independent sub-batches on separate HIP "
+                             "streams (NppAsyncVecEnvironment); not the headline metric"}
+        ab.close()
+
+    # secondary figure: the same K steps as launches of 50 steps each (npp_step_many): open-loop action sequences, as in
+    # batched checkpoint replay; wavefronts run through their steps without waiting for the slowest env of every step
+    many_rep = None
+    if secondaries and world == 1 and not gather_obs and not player_frame and not full_obs and args.open_loop_chunk > 0 and K >= args.open_loop_chunk:
+        mb = NppBatch(n, device=ctx["local_rank"], autoreset=True)
+        mb.load_levels(levels)
+        mb.assign_levels(env_level)
+        chunk = args.open_loop_chunk
+        mb.step_many(acts[:P + W])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done_steps = 0
+        for k0 in range(P + W, total - chunk + 1, chunk):
+            mb.step_many(acts[k0:k0 + chunk])
+            done_steps += chunk
+        torch.cuda.synchronize()
+        mdt = time.perf_counter() - t0
+        many_rep = {"steps_per_launch": chunk, "steps": done_steps, "value": n * done_steps / mdt, "unit": "env-steps/s",
+                    "note": "npp_step_many: open-loop action sequences (no observation between steps), per-step flags / "
+                            "rewards still written; not the headline metric"}
+        mb.close()
+    b.close()
+    del b
+    torch.cuda.empty_cache()
+
+    value = world * n * K / dt
+    pl = percentiles(step_us)
+    desc = DESCS[workload] % (n, len(levels))
+    if player_frame:
+        desc += ", player_frame 84x84 rendered every step"
+    if full_obs:
+        desc += (", full Dict obs every step: game_state, action_mask, entity_positions, spatial_context, switch_states, player_frame, "
+                 "global_view, reachability_features, mine_sdf_features (0 level(s) dropped)")
+    if gather_rep is not None:
+        desc += ", RCCL gather of the packed obs reported beside"
+    blk = {
+        "value": value, "unit": "env-steps/s", "steps": K, "ms_per_step": dt * 1e3 / K,
+        "config": {"workload": desc + ", frame_skip 4, uniform random actions, auto-reset", "envs_per_gpu": n, "frame_skip": FRAME_SKIP,
+                   "ticks_per_s": value * FRAME_SKIP, "preroll_steps": P, "player_frame": bool(player_frame or full_obs),
+                   "gather_obs": bool(gather_rep is not None), "terminated_frac_last_step": done_frac},
+        "launch_us": pl, "step_variant": step_variant, "stragglers": stragglers,
+        "roofline": hbm_roofline("npp_step_kernel", ALGO_BYTES_PER_ENV_STEP, n, pl, committed_traffic("step") or (None, None), STEP_NOTE),
+    }
+    if full_obs:
+        blk["config"]["full_obs"] = True
+    if render_us is not None:
+        pr = percentiles(render_us)
+        blk["roofline_render"] = hbm_roofline("npp_render_kernel", ALGO_BYTES_PER_FRAME, n, pr, committed_traffic("render") or (None, None),
+                                              "7056 B written + ~0.2 KB read per env; parity of the raster is unpinned (no cairo/cv2 reference frame)")
+        blk["roofline_render"]["launch_us"] = pr
+    if stage_us:
+        ok = {k: percentiles(v) for k, v in stage_us.items()}
+        blk["obs_kernels"] = dict(ok)
+        blk["obs_kernels"]["note"] = ("HIP-event time of each observation kernel per step on the launch stream; npp_step includes "
+                                      "spatial_context; reachability = table look-ups for the envs whose (cell, switch) key changed")
+        blk["roofline_render"] = hbm_roofline("npp_render_kernel", ALGO_BYTES_PER_FRAME, n, ok["player_frame"], (None, None),
+                                              "player_frame; raster parity unpinned (no cairo/cv2 reference frame)")
+        blk["roofline_global_view"] = hbm_roofline("npp_global_view_kernel", ALGO_BYTES_PER_GLOBAL_VIEW, n, ok["global_view"], (None, None),
+                                                   "17 600 B written per env (the per-level view it patches is read through L2)")
+        blk["roofline_reach"] = hbm_roofline("npp_reach_kernel", ALGO_BYTES_PER_REACH, n, ok["reachability"], (None, None),
+                                             "latency-bound table look-ups for the envs whose cache key changed")
+    if gather_rep is not None:
+        blk["with_obs_gather"] = gather_rep
+    if async_rep is not None:
+        blk["async_subbatches"] = async_rep
+    if many_rep is not None:
+        blk["open_loop_rollout"] = many_rep
+    blk["_levels"] = levels
+    return blk
 
 
 def main():
@@ -210,255 +502,52 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    from nclone_amd.engine import NppBatch
-    from nclone_amd import levels as level_sets
-
-    levels, tags = {"c0": level_sets.curriculum0_levels, "mines": level_sets.mine_levels, "doors": level_sets.door_levels,
-                    "zoo": level_sets.zoo_levels, "c3mixed": level_sets.c3_mixed_levels}[args.workload]()
-    n = args.envs_per_gpu
+    ctx = {"args": args, "rank": rank, "local_rank": local_rank, "world": world, "dist": dist, "n": args.envs_per_gpu,
+           "barrier": barrier, "max_over_ranks": max_over_ranks}
     K, W, P = args.steps, args.warmup, args.preroll
-    outputs = ["work"] + (["player_frame"] if args.player_frame else [])
-    dropped = 0
-    if args.full_obs:
-        from nclone_amd.engine import reach_level_info
-
-        keep = [i for i, m in enumerate(levels) if reach_level_info(m)["supported"]]
-        dropped = len(levels) - len(keep)
-        levels, tags = [levels[i] for i in keep], [tags[i] for i in keep]
-        outputs += ["spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features"]
-    STAGES = (("switch_states", lambda: b.switch_states()), ("player_frame", lambda: b.render_player_frame()),
-              ("global_view", lambda: b.render_global_view()), ("reachability", lambda: b.reachability())) if args.full_obs else ()
-    b = NppBatch(n, device=local_rank, autoreset=True, outputs=outputs)
-    b.load_levels(levels)
-    # 64 consecutive envs (one wavefront / workgroup) per level, levels repeated round-robin; with more ranks than one the
-    # global env index decides, so that 8 x 8192 envs cover all 512 levels of the mixed set twice
-    env_level = ((np.arange(n) + rank * n) // 64) % len(levels)
-    b.assign_levels(env_level)
-    rng = np.random.default_rng(rank + (2 if args.workload == "c3mixed" else 0))
-    total = P + W + K
-    acts = torch.from_numpy(rng.integers(0, 6, size=(total, n)).astype(np.uint8)).cuda()
-    work = torch.zeros((K, n), dtype=torch.int16, device="cuda")
-    stream = b.stream
-
-    def one(k, work_row=None):
-        b.step(acts[k], FRAME_SKIP, want_terminal=False, work_out=work_row)
-        if args.player_frame:
-            b.render_player_frame()
-        for _name, fn in STAGES:
-            fn()
-
-    def timed(k0, gather=None):
-        """K launches from step index k0 on, bracketed by barrier + synchronize; per-launch HIP events on the launch stream."""
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
-        mids = [torch.cuda.Event(enable_timing=True) for _ in range(K)] if args.player_frame else None
-        sevs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES))] for _ in range(K)]
-        barrier()
-        t0 = time.perf_counter()
-        evs[0].record(stream)
-        for k in range(K):
-            b.step(acts[k0 + k], FRAME_SKIP, want_terminal=False, work_out=work[k])
-            if mids is not None:
-                mids[k].record(stream)
-                b.render_player_frame()
-            for j, (_name, fn) in enumerate(STAGES):
-                sevs[k][j].record(stream)
-                fn()
-            if gather is not None:
-                gather()
-            evs[k + 1].record(stream)
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        if STAGES:
-            step_us = [evs[k].elapsed_time(sevs[k][0]) * 1e3 for k in range(K)]
-            render_us = None
-            for j, (name, _fn) in enumerate(STAGES):
-                stage_us[name] = [sevs[k][j].elapsed_time(sevs[k][j + 1] if j + 1 < len(STAGES) else evs[k + 1]) * 1e3 for k in range(K)]
-        elif mids is None:
-            step_us = [evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
-            render_us = None
+    single = args.workload is not None
+    head = run_workload(ctx, args.workload or "c0", K, W, P, player_frame=args.player_frame, full_obs=args.full_obs,
+                        gather_obs=args.gather_obs, secondaries=True)
+    others = {}
+    Ko = args.other_steps
+    if not single and Ko > 0 and not (args.player_frame or args.full_obs or args.gather_obs):
+        Wo = min(W, 50)
+        if world == 1:
+            # BASELINE configs 3, 4 (one GPU's shard) and 5 in the driver's default run
+            others["config3"] = run_workload(ctx, "mines", Ko, Wo, P, player_frame=True)
+            others["config4_shard"] = run_workload(ctx, "c3mixed", Ko, Wo, P)
+            others["config5_full_obs"] = run_workload(ctx, "doors", Ko, Wo, P, full_obs=True)
         else:
-            step_us = [evs[k].elapsed_time(mids[k]) * 1e3 for k in range(K)]
-            render_us = [mids[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(K)]
-        return dt, step_us, render_us
-
-    stage_us = {}
-    for k in range(P + W):
-        one(k)
-    dt, step_us, render_us = timed(P + W)
-    done_frac = float((b.flags & 3).ne(0).float().mean().item())
-    # build variant of the G = 16 step kernels picked by npp_step's autotuner during the pre-roll (include/npp_amd.h: npp_set_step_variant)
-    sv = b.step_variant()
-    step_variant = {"variant": int(sv[0]), "tuned": bool(sv[1]),
-                    "meaning": "0: 2 wavefronts/SIMD, 2 candidate slots; 1: 2 wavefronts/SIMD, 1 slot; 2: 1 wavefront/SIMD, 2 slots"}
-
-    # which levels own the slow launches: the env with the most depenetration iterations in each of the slowest 5 %
-    lt = np.asarray(step_us)
-    slow = np.argsort(lt)[-max(1, K // 20):]
-    wk = work[torch.from_numpy(np.sort(slow)).cuda()].cpu().numpy().astype(np.int64) & 0xffff
-    owners = env_level[np.argmax(wk, axis=1)]
-    ids, cnt = np.unique(owners, return_counts=True)
-    top = np.argsort(-cnt)[:6]
-    stragglers = {"launches": int(len(slow)), "iterations_max_env_mean": float(wk.max(axis=1).mean()),
-                  "iterations_all_envs_mean": float(wk.mean()),
-                  "levels": [{"level_id": int(ids[i]), "tag": tags[int(ids[i])], "launches": int(cnt[i])} for i in top]}
-
-    gather_rep = None
-    if args.gather_obs and dist is not None:
-        packed = b.out.packed()
-        if args.backend == "nccl":
-            gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device="cuda")
-
-            def gather():
-                dist.all_gather_into_tensor(gathered, packed)
-        else:   # gloo rehearsal: host tensors
-            gathered = torch.empty(world * packed.numel(), dtype=torch.uint8)
-            host = torch.empty(packed.numel(), dtype=torch.uint8)
-
-            def gather():
-                host.copy_(packed)
-                dist.all_gather_into_tensor(gathered, host)
-        for k in range(P, P + W):
-            one(k)
-            gather()
-        gdt, _, _ = timed(P + W, gather)
-        parts = b.out.split_packed(gathered, world)
-        ok = bool(torch.equal(parts["game_state"][rank].to(b.game_state.device), b.game_state))
-        gather_rep = {"value": world * n * K / gdt, "unit": "env-steps/s", "ms_per_step": gdt * 1e3 / K,
-                      "bytes_per_rank_per_step": int(packed.numel()), "collective": "all_gather_into_tensor (1 per step)",
-                      "own_shard_roundtrip_ok": ok,
-                      "fields": "game_state f32[41], entity_positions f32[6], reward f32, frames i16, action_mask i8[6], flags u8"}
-
-    # secondary figure: the asynchronous vector env (nclone_amd.async_env.NppAsyncVecEnvironment's engine): the same envs as S
-    # independent sub-batches, each stepped on its own HIP stream with no cross-stream synchronisation until the end.  A
-    # synchronous step lasts as long as its slowest env's serial fp64 chain; independent sub-batches fill that tail.
-    async_rep = None
-    S = args.async_streams
-    if S > 1 and world == 1 and n % (S * 64) == 0 and not args.gather_obs and not args.player_frame:
-        from nclone_amd.async_env import AsyncBatches
-
-        ab = AsyncBatches(n, S, device=local_rank, autoreset=True)
-        ab.load_levels(levels)
-        ab.assign_levels(env_level)
-        torch.cuda.synchronize()
-        views = [acts[:, k * (n // S):(k + 1) * (n // S)].contiguous() for k in range(S)]
-        for t in range(P + W):
-            ab.step_async([v[t] for v in views], FRAME_SKIP)
-        ab.wait()
-        t0 = time.perf_counter()
-        for t in range(P + W, total):
-            ab.step_async([v[t] for v in views], FRAME_SKIP)
-        ab.wait()
-        adt = time.perf_counter() - t0
-        async_rep = {"streams": S, "envs_per_stream": n // S, "value": n * K / adt, "unit": "env-steps/s",
-                     "ms_per_step_all_streams": adt * 1e3 / K,
-                     "note": "same envs, levels and actions as `value`, stepped as independent sub-batches on separate HIP "
-                             "streams (NppAsyncVecEnvironment); not the headline metric"}
-        ab.close()
-
-    # secondary figure: the same K steps as launches of 50 steps each (npp_step_many): open-loop action sequences, as in
-    # batched checkpoint replay; wavefronts run through their steps without waiting for the slowest env of every step
-    many_rep = None
-    if world == 1 and not args.gather_obs and not args.player_frame and args.open_loop_chunk > 0 and K >= args.open_loop_chunk:
-        mb = NppBatch(n, device=local_rank, autoreset=True)
-        mb.load_levels(levels)
-        mb.assign_levels(env_level)
-        chunk = args.open_loop_chunk
-        mb.step_many(acts[:P + W])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        done_steps = 0
-        for k0 in range(P + W, total - chunk + 1, chunk):
-            mb.step_many(acts[k0:k0 + chunk])
-            done_steps += chunk
-        torch.cuda.synchronize()
-        mdt = time.perf_counter() - t0
-        many_rep = {"steps_per_launch": chunk, "steps": done_steps, "value": n * done_steps / mdt, "unit": "env-steps/s",
-                    "note": "npp_step_many: open-loop action sequences (no observation between steps), per-step flags / "
-                            "rewards still written; not the headline metric"}
-        mb.close()
+            # the north-star multi-GPU config: the mixed set on N GPUs, with and without the RCCL observation gather
+            others["config4"] = run_workload(ctx, "c3mixed", Ko, Wo, P, gather_obs=True)
 
     if rank == 0:
-        value = world * n * K / dt
-        pl = percentiles(step_us)
-        launch_us = pl["mean"]   # HIP events on the launch stream: average duration per npp_step launch
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
-        desc = {
-            "c0": "config 2: %d envs/GPU, curriculum_level=0 (exit+switch only: 78 bc_replays maps + maze:tiny/hills:simple "
-                  "seeds 100001-100025 = %d levels x 64 envs), game_state+action_mask+entity_positions obs",
-            "mines": "config 3: %d envs/GPU, curriculum_level=2 (mines: 20 bc_replays maps + 44 generated corridor levels = %d "
-                     "levels x 64 envs)" + (", player_frame 84x84 rendered every step" if args.player_frame else ", raster off"),
-            "c3mixed": "config 4: %d envs/GPU (x n_gpus), curriculum_level=3 mixed map set (%d levels: c0 + mines + 320 generated "
-                       "simpler/simple levels) x 64 envs" + (", RCCL gather of the packed obs reported beside" if args.gather_obs else ""),
-            "doors": "config 5: %d envs/GPU, curriculum_level=4 (locked doors / switches, %d levels x 64 envs), "
-                     + ("full Dict obs every step: game_state, action_mask, entity_positions, spatial_context, switch_states, "
-                        "player_frame, global_view, reachability_features, mine_sdf_features (%d level(s) dropped: their "
-                        "reachability needs the reference's physics A* search)" % dropped if args.full_obs else "game_state obs"),
-            "zoo": "secondary level set 'zoo': %d envs/GPU on the %d entity-zoo maps x 64 envs",
-        }[args.workload] % (n, len(levels))
-        tr = committed_traffic("step") or (None, None)
+        levels = head.pop("_levels")
         line = {
             "metric": "env-steps/sec (whole node) at N parallel envs",
-            "value": value,
+            "value": head["value"],
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": dt * 1e3 / K,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {
-                "workload": desc + ", frame_skip 4, uniform random actions, auto-reset",
-                "envs_per_gpu": n,
-                "frame_skip": FRAME_SKIP,
-                "ticks_per_s": value * FRAME_SKIP,
-                "preroll_steps": P,
-                "player_frame": bool(args.player_frame),
-                "gather_obs": bool(gather_rep is not None),
-                "terminated_frac_last_step": done_frac,
-            },
-            "launch_us": pl,
-            "step_variant": step_variant,
-            "stragglers": stragglers,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": tr[0],
-                "traffic_source": tr[1],
-                "kernel": "npp_step_kernel",
-                "avg_launch_us": launch_us,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                "note": "issue-cadence-bound fp64 scalar chains (about 7k dependent flops per env-step; DESIGN.md 4.1): the HBM fraction is "
-                        "tiny by construction (SURVEY.md 8(d)); measured traffic above the algorithmic bytes is register-spill scratch of the "
-                        "2-wavefronts-per-SIMD build variants, a deliberate trade (DESIGN.md 4.1, build variants)",
-            },
         }
-        if render_us is not None:
-            pr = percentiles(render_us)
-            ach = ALGO_BYTES_PER_FRAME * n / (pr["mean"] * 1e-6) / 1e9
-            rt = committed_traffic("render") or (None, None)
-            line["roofline_render"] = {
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": rt[0], "traffic_source": rt[1], "kernel": "npp_render_kernel", "avg_launch_us": pr["mean"],
-                "launch_us": pr, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * n,
-                "note": "7056 B written + ~0.2 KB read per env; parity of the raster is unpinned (no cairo/cv2 reference frame)",
-            }
-        if stage_us:
-            line["obs_kernels"] = {k: percentiles(v) for k, v in stage_us.items()}
-            line["obs_kernels"]["note"] = ("HIP-event time of each observation kernel per step on the launch stream; npp_step includes "
-                                           "spatial_context; reachability = table look-ups for the envs whose (cell, switch) key changed")
-            line["config"]["full_obs"] = True
-        if gather_rep is not None:
-            line["with_obs_gather"] = gather_rep
-        if async_rep is not None:
-            line["async_subbatches"] = async_rep
-        if many_rep is not None:
-            line["open_loop_rollout"] = many_rep
+        for k, v in head.items():
+            if k not in line:
+                line[k] = v
+        if others:
+            for blk in others.values():
+                blk.pop("_levels", None)
+                blk["warmup"] = min(W, 50)
+            if world == 1:
+                line["other_configs"] = others
+            else:
+                line["config4"] = others["config4"]
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(levels)

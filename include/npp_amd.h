@@ -233,6 +233,20 @@ int npp_reach_compile(const double *map, int64_t n, int32_t *info, uint8_t *base
  * sdf_out f32[count][3] (may be NULL), status i32[count] (may be NULL; bit 0 as in npp_reachability, bit 1 = level unsupported). */
 int npp_reach_features_host(const double *map, int64_t n, const double *pos, const int32_t *mines, int count, float *out, float *sdf_out,
                             int32_t *status);
+/* Host-only: the tables behind the cache-miss branch of CachedPathDistanceCalculator.get_distance
+ * (graph/reachability/path_distance_calculator.py:1218-1485, physics A* :744-845), built for the exit door of levels whose door lies
+ * within 24 px (but not 12) of its switch -- there the reference's goal-id inference sends EVERY exit-door query down that branch.
+ * info i32[20]: miss branch active, number of goal nodes, switch and door share a 24-px cell, supported, then the goal node ids
+ * (-1 padded).  cgoal u8[3864]: index of the goal node find_goal_node_closest_to_start picks for a temp start node (255 = node
+ * not in the adjacency).  astar f64[16][3864]: _calculate_distance(start node, goal node) (NaN = pair not tabulated).
+ * mine_mult f64[3864]: MineProximityCostCache multiplier per node (1 = none).  Any pointer may be NULL. */
+int npp_reach_compile_miss(const double *map, int64_t n, int32_t *info, uint8_t *cgoal, double *astar, double *mine_mult);
+/* Host-only: npp_reach_features_host along a ROLLOUT -- the `count` positions are consecutive feature recomputations of one env,
+ * new_episode u8[count] marks the first recomputation after an episode reset (the path calculator's per-episode
+ * (start cell, goal cell) dictionary is emptied there, reachability_mixin.py:67-70); what the device keeps per env.  raw_out f64[count]
+ * (may be NULL): the dictionary's entry for the ninja's cell after each query (the raw A* cost; NaN = no entry). */
+int npp_reach_rollout_host(const double *map, int64_t n, const double *pos, const int32_t *mines, const uint8_t *new_episode, int count,
+                           float *out, int32_t *status, double *raw_out);
 
 /* Host-only: the zoo tables the level compiler derives from map_data.  edges_out: int32[2][89*51] grid-edge counters at
  * load (horizontal then vertical, key = x * 51 + y; tile edges of tile_segment_factory.py:283-302 plus closed doors,

@@ -68,6 +68,7 @@ struct npp_handle_s {
     uint32_t *d_rkey = nullptr, *s_rkey = nullptr;      // (ninja cell, exit_switch_activated) of the cached vector, 0 = none
     float *d_rcache = nullptr, *s_rcache = nullptr;     // [n][REACH_DIM + 1]
     int s_reach = 0;                                    // the snapshot slot holds a reachability cache
+    ReachMissDev rmiss = {nullptr, nullptr, nullptr, nullptr};   // per-env dictionary of the miss branch (levels with ReachHdr::miss_exit only)
     LevelHdr *d_hdr = nullptr;
     int n_words_max = 1;
     uint32_t hot_max = 0;      // largest staged-level size over the loaded set
@@ -238,16 +239,25 @@ int ensure_canvas(npp_handle h) {
     return NPP_OK;
 }
 
-int ensure_gv(npp_handle h) {
-    if (int rc = ensure_canvas(h)) return rc;
-    if (h->d_gv_h) return NPP_OK;
+int ensure_gv_tables(npp_handle h, float **gh) {
     const size_t nl = h->levels.size();
     HIP_TRY(h, hipMalloc((void **)&h->d_gv_v, nl * 176 * 100));
     HIP_TRY(h, hipMalloc((void **)&h->d_gv_p, nl * 600 * 1056 + 16));   // + 16: row slices are read as four aligned dwords
-    float *gh = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&gh, nl * 600 * 100 * sizeof(float)));
+    HIP_TRY(h, hipMalloc((void **)gh, nl * 600 * 100 * sizeof(float)));
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_gv_static(a, (int)nl, h->d_gv_p, gh, h->d_gv_v, h->stream));
+    HIP_TRY(h, launch_gv_static(a, (int)nl, h->d_gv_p, *gh, h->d_gv_v, h->stream));
+    return NPP_OK;
+}
+
+int ensure_gv(npp_handle h) {
+    if (int rc = ensure_canvas(h)) return rc;
+    if (h->d_gv_h) return NPP_OK;
+    float *gh = nullptr;
+    if (int rc = ensure_gv_tables(h, &gh)) {   // nothing half-built stays behind: the next call starts over (d_gv_h is the marker)
+        hipFree(h->d_gv_v); hipFree(h->d_gv_p); hipFree(gh);
+        h->d_gv_v = nullptr; h->d_gv_p = nullptr;
+        return rc;
+    }
     h->d_gv_h = gh;
     if (!h->d_gv_order) {
         HIP_TRY(h, hipMalloc((void **)&h->d_gv_order, (size_t)h->n * sizeof(uint32_t)));
@@ -265,48 +275,72 @@ int ensure_gv(npp_handle h) {
 
 void free_reach(npp_handle h) {
     hipFree(h->d_rhdr); hipFree(h->d_rblob); hipFree(h->d_rkey); hipFree(h->d_rcache); hipFree(h->s_rkey); hipFree(h->s_rcache);
+    hipFree(h->rmiss.stamp); hipFree(h->rmiss.raw); hipFree(h->rmiss.epoch); hipFree(h->rmiss.last_episode);
     h->d_rhdr = nullptr; h->d_rblob = nullptr; h->d_rkey = nullptr; h->d_rcache = nullptr; h->s_rkey = nullptr; h->s_rcache = nullptr;
+    h->rmiss = {nullptr, nullptr, nullptr, nullptr};
     h->s_reach = 0;
 }
 
 // The reachability tables (npp_reach.cpp) are built the first time the observation is asked for: ~1 ms of host work and
 // ~260 KB of HBM per level, which handles that never ask for it do not pay.
-int ensure_reach(npp_handle h) {
-    if (h->d_rhdr) return NPP_OK;
-    const size_t nl = h->levels.size();
-    std::vector<ReachHdr> hdrs(nl);
-    std::vector<unsigned char> blob;
-    for (size_t i = 0; i < nl; i++) {
-        ReachBuilt R;
-        build_reach(h->levels[i], R);
-        if (!R.hdr.supported)
-            return fail(h, NPP_ERR_UNSUPPORTED, "npp_reachability: level " + std::to_string(i) + ": " + R.note +
-                                                    " (outside the restated part of the reference's reachability code, see DESIGN.md)");
-        pack_reach(R, hdrs[i], blob);
-    }
-    const size_t N = (size_t)h->n;
+int ensure_reach_alloc(npp_handle h, const std::vector<ReachHdr> &hdrs, const std::vector<unsigned char> &blob, bool any_miss) {
+    const size_t N = (size_t)h->n, nl = hdrs.size();
     HIP_TRY(h, hipMalloc((void **)&h->d_rblob, blob.size() + 16));
     HIP_TRY(h, hipMemcpy(h->d_rblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMalloc((void **)&h->d_rkey, sizeof(uint32_t) * N));
     HIP_TRY(h, hipMemset(h->d_rkey, 0, sizeof(uint32_t) * N));
     HIP_TRY(h, hipMalloc((void **)&h->d_rcache, sizeof(float) * (REACH_DIM + 1) * N));
     HIP_TRY(h, hipMemset(h->d_rcache, 0, sizeof(float) * (REACH_DIM + 1) * N));
+    if (any_miss) {   // 13.2 KB per env: 108 MB at 8192 envs
+        HIP_TRY(h, hipMalloc((void **)&h->rmiss.stamp, sizeof(uint32_t) * REACH_CELLS * N));
+        HIP_TRY(h, hipMemset(h->rmiss.stamp, 0, sizeof(uint32_t) * REACH_CELLS * N));
+        HIP_TRY(h, hipMalloc((void **)&h->rmiss.raw, sizeof(double) * REACH_CELLS * N));
+        HIP_TRY(h, hipMalloc((void **)&h->rmiss.epoch, sizeof(uint32_t) * N));
+        HIP_TRY(h, hipMemset(h->rmiss.epoch, 0, sizeof(uint32_t) * N));
+        HIP_TRY(h, hipMalloc((void **)&h->rmiss.last_episode, sizeof(uint32_t) * N));
+        HIP_TRY(h, hipMemset(h->rmiss.last_episode, 0xff, sizeof(uint32_t) * N));
+    }
     ReachHdr *d = nullptr;
     HIP_TRY(h, hipMalloc((void **)&d, sizeof(ReachHdr) * nl));
+    h->d_rhdr = d;
     HIP_TRY(h, hipMemcpy(d, hdrs.data(), sizeof(ReachHdr) * nl, hipMemcpyHostToDevice));
-    h->d_rhdr = d;   // last: marks the tables as complete
     return NPP_OK;
+}
+
+int ensure_reach(npp_handle h) {
+    if (h->d_rhdr) return NPP_OK;
+    const size_t nl = h->levels.size();
+    std::vector<ReachHdr> hdrs(nl);
+    std::vector<unsigned char> blob;
+    bool any_miss = false;
+    for (size_t i = 0; i < nl; i++) {
+        ReachBuilt R;
+        build_reach(h->levels[i], R);
+        if (!R.hdr.supported)
+            return fail(h, NPP_ERR_UNSUPPORTED, "npp_reachability: level " + std::to_string(i) + ": " + R.note +
+                                                    " (outside the restated part of the reference's reachability code, see DESIGN.md)");
+        any_miss = any_miss || R.hdr.miss_exit;
+        pack_reach(R, hdrs[i], blob);
+    }
+    const int rc = ensure_reach_alloc(h, hdrs, blob, any_miss);
+    if (rc != NPP_OK) {   // a failed allocation / copy must not leave half a table set behind (d_rhdr is the "complete" marker)
+        const std::string msg = h->err;
+        free_reach(h);
+        h->err = msg;
+    }
+    return rc;
 }
 
 // `fresh` = the entities are created for the first time since the level was assigned (the state a replay starts from);
 // any later reset is a Simulator.reset(), after which Entity.index no longer starts at 0 (see ZOO_HEAD in npp_internal.hpp)
-int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh, int fast = 0) {
+int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh, int fast = 0, int automatic = 0) {
     if (!h) return NPP_ERR_INVALID;
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reset: no levels loaded");
     ON_DEVICE(h);
     KernelArgs a = base_args(h);
     a.reset_fresh = fresh;
     a.fast_reset = fresh ? 0 : fast;
+    a.reset_auto = automatic;
     if (env_mask) {
         HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
         a.reset_mask = h->d_mask;
@@ -434,7 +468,7 @@ int npp_restore(npp_handle h, const uint8_t *env_mask) {
     }
     HIP_TRY(h, launch_restore(a, h->s_f64, h->s_u32, h->s_ent, h->s_sc, h->d_zoo ? h->s_zoo : nullptr, h->stream));
     if (h->d_rkey)   // no cache in the snapshot (taken before the first npp_reachability): the restored envs start without one
-        HIP_TRY(h, launch_reach_restore(a, h->s_reach ? h->s_rkey : nullptr, h->s_rcache, h->d_rkey, h->d_rcache, h->stream));
+        HIP_TRY(h, launch_reach_restore(a, h->s_reach ? h->s_rkey : nullptr, h->s_rcache, h->d_rkey, h->d_rcache, h->rmiss, h->stream));
     if (env_mask) HIP_TRY(h, hipStreamSynchronize(h->stream));
     // the restored zoo blocks carry the repositioning flags / coordinates of the snapshot (head words 3..7): the host's
     // view of them (which decides whether the zoo kernels run) is restored with them
@@ -628,7 +662,7 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
         KernelArgs a = base_args(h);
         HIP_TRY(h, hipMemcpy(h->d_mask, mask.data(), (size_t)h->n, hipMemcpyHostToDevice));
         a.reset_mask = h->d_mask;
-        HIP_TRY(h, launch_reach_restore(a, nullptr, nullptr, h->d_rkey, h->d_rcache, h->stream));
+        HIP_TRY(h, launch_reach_restore(a, nullptr, nullptr, h->d_rkey, h->d_rcache, h->rmiss, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return reset_impl(h, mask.data(), 1);
@@ -640,7 +674,9 @@ int npp_reset_ex(npp_handle h, const uint8_t *env_mask, int mode) {
     if (!h) return NPP_ERR_INVALID;
     if (mode < 0 || mode > 2) return fail(h, NPP_ERR_INVALID, "npp_reset_ex: mode must be 0, 1 or 2");
     const int fast = mode == 2 || (mode == 0 && (h->flags & NPP_FLAG_FAST_RESET));
-    return reset_impl(h, env_mask, 0, fast ? 1 : 0);
+    // mode 0 follows NppEnvironment.reset: the first reset after a level assignment reloads the map (Simulator.reset), later ones
+    // are fast resets; the per-env "no reset yet" bit lives in the state planes (npp_kernels.hip: Nj::fastord bit 1)
+    return reset_impl(h, env_mask, 0, fast ? 1 : 0, mode == 0 ? 1 : 0);
 }
 
 int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
@@ -862,7 +898,7 @@ int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t
     ON_DEVICE(h);
     if (int rc = ensure_reach(h)) return rc;
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, d_features, d_mine_sdf, d_status, h->stream));
+    HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, h->stream));
     return NPP_OK;
 }
 

@@ -108,6 +108,8 @@ struct KernelArgs {
     int zoo_active;       // 1: some env currently plays a level with zoo entities -> the zoo step kernel runs
     int reset_fresh;      // reset kernel: 1 = this reset is the first creation after a (re)assignment of levels
     int fast_reset;       // reset kernel: this reset is a Simulator.fast_reset; step kernels: auto-resets are fast resets
+    int reset_auto;       // reset kernel, with fast_reset: envs without a Simulator.reset since their level assignment (state word E
+                          // bit 18) get a full reset instead -- the reference env's first reset() (npp_environment.py:518-557)
     // npp_step only (null elsewhere): heavy-first launch order of the workgroups -- wg_order[blockIdx.x] is the block of envs this
     // workgroup steps, wg_cost[block] the shader clocks its last launch took (launch_cost_order rebuilds the order from the costs)
     const uint32_t *wg_order;
@@ -162,11 +164,18 @@ hipError_t launch_full_frame(const KernelArgs &a, int env0, int count, uint8_t *
 hipError_t launch_switch_states(const KernelArgs &a, float *d_out, hipStream_t s);
 // npp_reach_kernel.hip (tables: npp_reach.hpp)
 struct ReachHdr;
-hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key, float *cache, float *out,
-                        float *sdf_out, int32_t *status, hipStream_t s);
+// per-env arrays behind ReachMiss (npp_reach_features.hpp): allocated only when a loaded level takes the reference's miss branch
+struct ReachMissDev {
+    uint32_t *stamp;   // [n][REACH_CELLS]
+    double *raw;       // [n][REACH_CELLS]
+    uint32_t *epoch;   // [n] current epoch of the env's entries (stamp == epoch: live); 0 = never called
+    uint32_t *last_episode;   // [n] episode counter (state word E bits 19-31) seen at the last call
+};
+hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key, float *cache,
+                        const ReachMissDev &md, float *out, float *sdf_out, int32_t *status, hipStream_t s);
 // envs selected by a.reset_mask (NULL = all): key / cache <- the snapshot's, or "no cached vector" when src_key == NULL
 hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, const float *src_cache, uint32_t *key, float *cache,
-                                hipStream_t s);
+                                const ReachMissDev &md, hipStream_t s);
 // order <- the indices 0 .. n - 1 sorted by cost, heaviest first (128 logarithmic bins; any costs give a permutation)
 hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, int fold, hipStream_t s);
 hipError_t launch_tile_tables(hipStream_t s);   // per-device tile gray tables of the player_frame kernel

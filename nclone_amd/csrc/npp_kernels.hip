@@ -81,8 +81,14 @@ struct Nj {
     int jbuf, fbuf, wbuf, lbuf, cause, timpact;
     int jdur, fcount, ccount, pstate, fair, scf, frame, gold, doors, pcell;
     int work;   // depenetration iterations applied since the step began (npp_step_out.d_work; not part of the state)
-    int fastord;   // 1 after a Simulator.fast_reset: the cell lists are in entity_dic order (nsim.py:124-140)
+    int fastord;   // bit 0: set after a Simulator.fast_reset -- the cell lists are in entity_dic order (nsim.py:124-140);
+                   // bit 1: the level was assigned and no Simulator.reset has run since (the state of a fresh NppEnvironment after
+                   // __init__'s load_map, base_environment.py:318): the next automatic reset is a FULL one, as in the reference, whose
+                   // first reset() finds _last_reset_map_name None and reloads the map (npp_environment.py:518-557);
+                   // bits 2-14: episode counter mod 8192, bumped by every reset (the reachability kernel drops the env's per-episode
+                   // path-distance cache when it changes: reachability_mixin.py:67-70 clears the calculator at every reset)
 };
+DEV int next_episode(int fastord) { return (((fastord >> 2) + 1) & 0x1fff) << 2; }
 
 struct Lv {
     const uint16_t *seg_start;
@@ -159,7 +165,7 @@ DEV void load_state(const KernelArgs &a, int e, Nj &n) {
     n.frame = D & 0xffff; n.gold = (D >> 16) & 255; n.doors = D >> 24;
     n.pcell = E & 0xffff;
     n.scvalid = (E >> 16) & 1;
-    n.fastord = (E >> 17) & 1;
+    n.fastord = (E >> 17) & 0x7fff;
     n.work = 0;
 }
 
@@ -1551,9 +1557,12 @@ DEV void block_store_rows(const uint32_t *stage, uint32_t *dst_block, int width,
 // Executed by all lanes of the env's group on identical data (the LDS updates are idempotent).
 template <bool ZOO>
 DEV void episode_reset(const KernelArgs &a, const LevelHdr &H, Lv &lv, Zoo &z, Nj &n, EntBits eb, int nw, int r, int G) {
+    const bool fast = a.fast_reset && !(n.fastord & 2);   // the first reset after a level assignment is a Simulator.reset
+    const int episode = next_episode(n.fastord);
     spawn_state(lv, n);
-    if (a.fast_reset) {
-        n.fastord = 1;
+    n.fastord = episode;
+    if (fast) {
+        n.fastord |= 1;
         lv.perm = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_perm);
         const uint32_t *keep = reinterpret_cast<const uint32_t *>(a.blob + H.off_keep_words);
         for (int w = 0; w < nw; w++) {
@@ -1674,9 +1683,9 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     Nj n;
     load_state(a, e, n);
     // list order inside a cell: map order after Simulator.reset, entity_dic order after a fast reset
-    lv.perm = reinterpret_cast<const uint16_t *>(a.blob + (n.fastord ? H.off_ent_perm : H.off_ent_ident));
+    lv.perm = reinterpret_cast<const uint16_t *>(a.blob + ((n.fastord & 1) ? H.off_ent_perm : H.off_ent_ident));
     if constexpr (ZOO) {
-        if (n.fastord) z.ent_ord = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_rank);
+        if (n.fastord & 1) z.ent_ord = reinterpret_cast<const uint16_t *>(a.blob + H.off_ent_rank);
     }
     const int nw = (int)lv.n_words;
     if (r == 0)
@@ -1850,8 +1859,12 @@ __global__ __launch_bounds__(64) void npp_reset_kernel(KernelArgs a) {
     lv.spawn_x = H.spawn_x; lv.spawn_y = H.spawn_y;
     Nj n;
     spawn_state(lv, n);
-    const bool fast = a.fast_reset != 0;   // Simulator.fast_reset (nsim.py:78-140); the host never asks for it on a fresh assignment
-    n.fastord = fast ? 1 : 0;
+    // Simulator.fast_reset (nsim.py:78-140).  a.reset_auto (npp_reset / npp_reset_ex mode 0 under NPP_FLAG_FAST_RESET): envs that
+    // have not had a Simulator.reset since their level was assigned get a full one, like the reference env's first reset()
+    const uint32_t oldE = a.u32[U_E * (size_t)a.n + env];
+    const bool first = ((oldE >> 18) & 1u) != 0;
+    const bool fast = a.fast_reset != 0 && !(a.reset_auto && first);
+    n.fastord = next_episode((int)((oldE >> 17) & 0x7fff)) | (a.reset_fresh ? 2 : (fast ? (1 | (first ? 2 : 0)) : 0));
     store_state(a, env, n);
     const uint32_t *init = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
     const uint32_t *keep = reinterpret_cast<const uint32_t *>(a.blob + H.off_keep_words);

@@ -244,6 +244,199 @@ void multi_hop(const std::vector<int16_t> &parent, int node, double &ox, double 
     ox = tx / mag; oy = ty / mag;
 }
 
+
+// ---- the cache-miss branch of CachedPathDistanceCalculator.get_distance (path_distance_calculator.py:1218-1485) ------------------
+// CPython's float ** float is libm pow(); glibc's pow(x, 2.0) / pow(x, 0.5) differ from x * x / sqrt(x) in the last bit for ~0.1 % of
+// the inputs, and the compiler would fold a direct call: go through a volatile pointer.
+double (*volatile py_pow)(double, double) = static_cast<double (*)(double, double)>(std::pow);
+
+// MineProximityCostCache._precompute_mine_proximity_costs (mine_proximity_cache.py:70-196): node positions are in tile-data space,
+// mine positions in world space, and the reference subtracts them as they are
+void mine_multipliers(const Graph &fin, const CompiledLevel &L, const std::vector<int> &mines, std::vector<double> &mult) {
+    mult.assign(RNODES, 1.0);
+    if (mines.empty()) return;
+    for (int id = 0; id < RNODES; id++) {
+        if (!fin.in[id]) continue;
+        double best = INFINITY;
+        for (int s : mines) {
+            const double dx = (double)reach_node_x(id) - L.ent_x[s], dy = (double)reach_node_y(id) - L.ent_y[s];
+            const double d = py_pow(dx * dx + dy * dy, 0.5);
+            best = d < best ? d : best;   // min(min_distance, distance)
+        }
+        if (best < 48.0) {   // MINE_HAZARD_RADIUS
+            const double pf = 1.0 - (best / 48.0);
+            mult[id] = 1.0 + py_pow(pf, 2.0) * (1.1 - 1.0);   // MINE_HAZARD_COST_MULTIPLIER - 1.0
+        }
+    }
+}
+
+struct AStarCtx {
+    const Graph *adj;                  // masked + flood-filled adjacency (neighbour lists)
+    const std::vector<uint8_t> *ph;    // physics cache (base graph): bit 0 grounded, bit 1 walled
+    const std::vector<double> *mine;   // mine proximity multiplier per node
+    const std::vector<float> *grad;    // mine SDF gradient grid [SDF_H][SDF_W][2], empty = zeros
+};
+
+// _get_aerial_chain_multiplier (pathfinding_utils.py:80-111)
+double aerial_chain_multiplier(int chain) {
+    if (chain <= 2) return py_pow(3.0, (double)(chain + 1));
+    return 500.0 * py_pow(3.0, (double)(chain - 2));
+}
+
+// _calculate_physics_aware_cost (pathfinding_utils.py:174-539) with ninja_velocity = None and hazard_cost_multiplier = None, which is
+// how compute_reachability_features_from_graph reaches it.  parent / grandparent: node ids, -1 = None.
+double physics_cost(const AStarCtx &C, int src, int dst, int parent, int grandparent, int chain) {
+    const int sx = reach_node_x(src), sy = reach_node_y(src), tx = reach_node_x(dst), ty = reach_node_y(dst);
+    const int dx = tx - sx, dy = ty - sy;
+    const bool src_g = ((*C.ph)[src] & 1) != 0, dst_g = ((*C.ph)[dst] & 1) != 0, src_w = ((*C.ph)[src] & 2) != 0;
+    bool x_change = false, y_to_rising = false, from_hair = false;
+    int pdx = 0, pdy = 0, px = 0;
+    if (parent >= 0) {
+        px = reach_node_x(parent);
+        pdx = sx - px; pdy = sy - reach_node_y(parent);
+        if (pdx != 0 && dx != 0) x_change = (pdx > 0) != (dx > 0);
+        if (pdy >= 0 && dy < 0) y_to_rising = true;
+        if (pdy == 0 && !src_g) from_hair = true;
+    }
+    const double base_cost = (dx != 0 && dy != 0) ? 1.414 : 1.0;
+    double mult;
+    if (dx != 0 && dy > 0 && !src_g && !src_w) mult = 0.15;
+    else if (dx != 0 && dy < 0 && !src_g && src_w) {
+        if (from_hair || y_to_rising) mult = INFINITY;
+        else if (x_change) mult = 1.5;
+        else mult = 1.0;
+    } else if (dx != 0 && dy < 0 && src_g) mult = 0.2;
+    else if (dx != 0 && dy < 0 && !src_g && !src_w) {
+        if (from_hair) mult = INFINITY;
+        else if (chain > 0 && parent >= 0 && pdy >= 0) mult = INFINITY;
+        else if (y_to_rising) mult = INFINITY;
+        else mult = 1.0;   // both remaining branches of the reference
+    } else if (dy < 0) {
+        if (src_g) mult = 0.7;
+        else if (src_w) mult = (from_hair || y_to_rising) ? INFINITY : 1.2;
+        else if (from_hair) mult = INFINITY;
+        else if (chain > 0 && parent >= 0 && pdy >= 0) mult = INFINITY;
+        else if (y_to_rising) mult = INFINITY;
+        else mult = aerial_chain_multiplier(chain);
+    } else if (dy > 0) mult = 0.5;
+    else {
+        if (src_g && dst_g) mult = 0.15;
+        else if (x_change && !src_g && !src_w) mult = 1.5;
+        else if (!src_g && !src_w) mult = 0.5;
+        else mult = 1.0;
+    }
+    double momentum = 1.0;
+    if (dy == 0 && src_g && dst_g && grandparent >= 0 && parent >= 0) {
+        const int recent = sx - px, prev = px - reach_node_x(grandparent);
+        if (recent * prev > 0 && std::abs(recent) >= 12 && dx != 0) {
+            const int dir = recent < 0 ? -1 : 1;
+            momentum = dir * dx > 0 ? 0.7 : 2.5;
+        }
+    }
+    double mine = (*C.mine)[dst];
+    if (parent >= 0 && !C.grad->empty()) {   // velocity-aware mine cost from the SDF gradient at the destination (tile-data coordinates)
+        int col = (int)((double)tx / 12.0), row = (int)((double)ty / 12.0);
+        col = col < 0 ? 0 : (col > SDF_W - 1 ? SDF_W - 1 : col);
+        row = row < 0 ? 0 : (row > SDF_H - 1 ? SDF_H - 1 : row);
+        const double gx = (double)(*C.grad)[(row * SDF_W + col) * 2], gy = (double)(*C.grad)[(row * SDF_W + col) * 2 + 1];
+        if (gx * gx + gy * gy > 0.0001) {
+            const double vmag = py_pow((double)(dx * dx + dy * dy), 0.5);
+            const double vx = (double)dx / vmag, vy = (double)dy / vmag;
+            const double toward = -(vx * gx + vy * gy);
+            if (toward > 0.3) mine *= 1.0 + toward * vmag * 0.16667;
+        }
+    }
+    return base_cost * mult * momentum * mine * 1.0;
+}
+
+struct AQ {
+    double f, g;
+    int x, y, id;
+    bool operator<(const AQ &o) const {   // max-heap of std::priority_queue inverted: heapq order of (f, g, (x, y))
+        if (f != o.f) return f > o.f;
+        if (g != o.g) return g > o.g;
+        if (x != o.x) return x > o.x;
+        return y > o.y;
+    }
+};
+
+// CachedPathDistanceCalculator._calculate_distance -> _astar_distance (path_distance_calculator.py:581-657, 744-845)
+struct AStar {
+    std::vector<double> g;
+    std::vector<uint8_t> has, visited;
+    std::vector<int16_t> parent, grand, chain;
+    AStar() : g(RNODES), has(RNODES), visited(RNODES), parent(RNODES), grand(RNODES), chain(RNODES) {}
+    double run(const AStarCtx &C, int start, int goal) {
+        const Graph &A = *C.adj;
+        if (!A.in[start] || !A.in[goal]) return INFINITY;
+        if (start == goal) return 0.0;
+        std::fill(has.begin(), has.end(), 0);
+        std::fill(visited.begin(), visited.end(), 0);
+        const int gx = reach_node_x(goal), gy = reach_node_y(goal);
+        auto h = [&](int id) { return (double)(std::abs(reach_node_x(id) - gx) + std::abs(reach_node_y(id) - gy)); };
+        std::priority_queue<AQ> open;
+        open.push({h(start), 0.0, reach_node_x(start), reach_node_y(start), start});
+        g[start] = 0.0; has[start] = 1; parent[start] = -1; grand[start] = -1; chain[start] = 0;
+        while (!open.empty()) {
+            const AQ cur = open.top();
+            open.pop();
+            if (visited[cur.id]) continue;
+            visited[cur.id] = 1;
+            if (cur.id == goal) return cur.g;
+            const bool grounded = ((*C.ph)[cur.id] & 1) != 0;
+            const int cchain = chain[cur.id], cpar = parent[cur.id], cgrand = grand[cur.id];
+            const int i = cur.id / RH, j = cur.id % RH;
+            for (int d = 0; d < 8; d++) {
+                if (!A.edge(cur.id, d)) continue;
+                const int nb = nid(i + DX[d], j + DY[d]);
+                if (visited[nb]) continue;
+                // _violates_horizontal_rule (pathfinding_utils.py:582-630)
+                if (DY[d] == 0 && !(grounded && ((*C.ph)[nb] & 1)) && cpar >= 0 && reach_node_y(cpar) == reach_node_y(cur.id) &&
+                    reach_node_x(cpar) != reach_node_x(cur.id))
+                    continue;
+                const int nchain = (!grounded && DY[d] < 0) ? cchain + 1 : 0;
+                const double cost = physics_cost(C, cur.id, nb, cpar, cgrand, cchain);
+                const double tg = cur.g + cost;
+                if (!has[nb] || tg < g[nb]) {
+                    g[nb] = tg; has[nb] = 1;
+                    parent[nb] = (int16_t)cur.id; grand[nb] = (int16_t)cpar; chain[nb] = (int16_t)nchain;
+                    open.push({tg + h(nb), tg, reach_node_x(nb), reach_node_y(nb), nb});
+                }
+            }
+        }
+        return INFINITY;
+    }
+};
+
+// find_goal_node_closest_to_start with get_distance's ladder of search radii (path_distance_calculator.py:1290-1372): the nodes
+// within the radius of the goal (dict order), those within the entity radius preferred, the one closest to the start node wins
+int goal_node_for_start(const std::vector<int> &order, int qx, int qy, int entity_r, int start) {
+    static const double RADII[3] = {-1.0, 48.0, 150.0};
+    const long sx = reach_node_x(start), sy = reach_node_y(start);
+    for (int step = 0; step < 3; step++) {
+        const double R = RADII[step] < 0.0 ? 10.0 + (double)entity_r : RADII[step];
+        int best = -1, best_o = -1;
+        long bd = 0, bdo = 0;
+        for (int id : order) {
+            const long ex = reach_node_x(id) - qx, ey = reach_node_y(id) - qy, d2 = ex * ex + ey * ey;
+            if ((double)d2 > R * R) continue;
+            const long tx = reach_node_x(id) - sx, ty = reach_node_y(id) - sy, ds = tx * tx + ty * ty;
+            if (d2 <= (long)entity_r * entity_r) {   // ((..) ** 0.5 <= entity_radius on integer sums)
+                if (best_o < 0 || ds < bdo) { best_o = id; bdo = ds; }
+            } else if (best < 0 || ds < bd) { best = id; bd = ds; }
+        }
+        if (best_o >= 0) return best_o;
+        if (best >= 0) return best;
+    }
+    int best = -1;
+    long bd = 0;
+    for (int id : order) {   // "ANY closest node in the entire adjacency graph"
+        const long ex = reach_node_x(id) - qx, ey = reach_node_y(id) - qy, d2 = ex * ex + ey * ey;
+        if (best < 0 || d2 < bd) { best = id; bd = d2; }
+    }
+    return best;
+}
+
 }  // namespace
 
 bool build_reach(const double *map, int64_t n, ReachBuilt &R, std::string &err) {
@@ -386,10 +579,9 @@ void build_reach(const CompiledLevel &L, ReachBuilt &R) {
     H.exit_gid = 1;
     if (H.sw_valid && H.ex_valid && sw >= 0 && dr >= 0 && std::fabs(L.ent_x[sw] - H.goal_x[1]) < 24.0 && std::fabs(L.ent_y[sw] - H.goal_y[1]) < 24.0) {
         H.exit_gid = 0;
-        if (std::abs(H.goal_x[0] - H.goal_x[1]) > 12 || std::abs(H.goal_y[0] - H.goal_y[1]) > 12) {
-            H.supported = 0;
-            R.note = "exit door within 24 px of the switch: the reference validates against the wrong goal and leaves the level cache";
-        }
+        // validation against the switch's cached position (path_distance_calculator.py:1046-1072) fails beyond 12 px: every exit-door
+        // query then falls through to the cache-miss branch -- tabulated at the end of this function
+        if (std::abs(H.goal_x[0] - H.goal_x[1]) > 12 || std::abs(H.goal_y[0] - H.goal_y[1]) > 12) H.miss_exit = 1;
     }
     // ---- feature 3 and features 25-28 (static)
     H.exit_reachable = (H.ex_valid && H.goal_node[1] >= 0) ? 1.f : 0.f;
@@ -433,6 +625,54 @@ void build_reach(const CompiledLevel &L, ReachBuilt &R) {
                 }
             }
     }
+    // ---- the cache-miss branch for the exit door (see ReachHdr::miss_exit).  Everything it computes is a function of the level and
+    //      of the ninja position alone: goal node = f(temp start node), cost = physics A* (start node -> goal node).  The per-episode
+    //      (start cell, goal cell) cache in front of it is the only history, and lives per env on the device.
+    {
+        std::vector<int> all = mines1;
+        all.insert(all.end(), mines21.begin(), mines21.end());
+        mine_multipliers(fin, L, all, R.mine_mult);
+    }
+    H.sw_alias = (H.sw_valid && H.ex_valid && H.goal_x[0] / 24 == H.goal_x[1] / 24 && H.goal_y[0] / 24 == H.goal_y[1] / 24) ? 1u : 0u;
+    if (H.miss_exit && H.supported) {
+        std::vector<int> order;
+        for (int id = 0; id < RNODES; id++)
+            if (fin.in[id]) order.push_back(id);
+        std::sort(order.begin(), order.end(), [](int a, int b) { return reach_order_key(a) < reach_order_key(b); });
+        R.cgoal.assign(RNODES, 0xff);
+        const int qx = H.goal_x[1] - 24, qy = H.goal_y[1] - 24;
+        std::vector<int> cand;
+        for (int t : order) {
+            const int c = goal_node_for_start(order, qx, qy, 12, t);
+            size_t k = std::find(cand.begin(), cand.end(), c) - cand.begin();
+            if (k == cand.size()) cand.push_back(c);
+            R.cgoal[t] = (uint8_t)(k < 0xff ? k : 0xfe);
+        }
+        if (cand.size() > (size_t)REACH_MAX_CAND) {
+            H.supported = 0;
+            R.note = "more than 16 goal nodes around the exit door";
+        } else {
+            H.n_cand = (uint32_t)cand.size();
+            for (size_t k = 0; k < cand.size(); k++) H.cand[k] = cand[k];
+            R.astar.assign(cand.size() * (size_t)RNODES, NAN);
+            const AStarCtx C{&fin, &R.phys, &R.mine_mult, &R.grad};
+            AStar A;
+            // start node and temp start node of one query both lie within a tile of the ninja: tabulate every start node within
+            // four lattice steps of a temp start node that selects the goal node (anything else reads NaN -> status bit 0)
+            for (size_t k = 0; k < cand.size(); k++) {
+                std::vector<uint8_t> want(RNODES, 0);
+                for (int t : order) {
+                    if (R.cgoal[t] != k) continue;
+                    const int ti = t / RH, tj = t % RH;
+                    for (int i = std::max(0, ti - 4); i <= std::min(RW - 1, ti + 4); i++)
+                        for (int j = std::max(0, tj - 4); j <= std::min(RH - 1, tj + 4); j++)
+                            if (fin.in[nid(i, j)]) want[nid(i, j)] = 1;
+                }
+                for (int s2 : order)
+                    if (want[s2]) R.astar[k * RNODES + s2] = A.run(C, s2, cand[k]);
+            }
+        }
+    }
 }
 
 // pack one level's tables behind `hdr` into `blob` (16-byte aligned sections); offsets are relative to the blob start
@@ -462,6 +702,11 @@ void pack_reach(const ReachBuilt &R, ReachHdr &hdr, std::vector<unsigned char> &
     hdr.off_mh = append(m2.data(), 32 * RNODES);
     hdr.off_mine_mask = append(R.mine_mask.data(), 4 * R.mine_mask.size());
     hdr.n_words = (uint32_t)R.mine_mask.size();
+    hdr.off_cgoal = hdr.off_astar = 0;
+    if (R.hdr.miss_exit && !R.astar.empty()) {
+        hdr.off_cgoal = append(R.cgoal.data(), RNODES);
+        hdr.off_astar = append(R.astar.data(), 8 * R.astar.size());
+    }
     hdr.off_sdf = hdr.off_grad = 0;
     if (R.has_sdf) {
         hdr.off_sdf = append(R.sdf.data(), 4 * R.sdf.size());
@@ -523,6 +768,53 @@ int npp_reach_features_host(const double *map, int64_t n, const double *pos, con
                                       out + (size_t)k * REACH_DIM, sd);
         if (sdf_out) { sdf_out[3 * k] = sd[0]; sdf_out[3 * k + 1] = sd[1]; sdf_out[3 * k + 2] = sd[2]; }
         if (status) status[k] = st | (H.supported ? 0 : 2);
+    }
+    return NPP_OK;
+}
+
+int npp_reach_compile_miss(const double *map, int64_t n, int32_t *info, uint8_t *cgoal, double *astar, double *mine_mult) {
+    if (!map) return NPP_ERR_INVALID;
+    ReachBuilt R;
+    std::string err;
+    if (!build_reach(map, n, R, err)) return NPP_ERR_INVALID;
+    const ReachHdr &H = R.hdr;
+    if (info) {
+        info[0] = (int32_t)H.miss_exit; info[1] = (int32_t)H.n_cand; info[2] = (int32_t)H.sw_alias; info[3] = (int32_t)H.supported;
+        for (int k = 0; k < REACH_MAX_CAND; k++) info[4 + k] = k < (int)H.n_cand ? H.cand[k] : -1;
+    }
+    if (cgoal) {
+        if (R.cgoal.empty()) std::memset(cgoal, 0xff, RNODES);
+        else std::memcpy(cgoal, R.cgoal.data(), RNODES);
+    }
+    if (astar && !R.astar.empty()) std::memcpy(astar, R.astar.data(), 8 * R.astar.size());
+    if (mine_mult) std::memcpy(mine_mult, R.mine_mult.data(), 8 * RNODES);
+    return NPP_OK;
+}
+
+int npp_reach_rollout_host(const double *map, int64_t n, const double *pos, const int32_t *mines, const uint8_t *new_episode, int count,
+                           float *out, int32_t *status, double *raw_out) {
+    if (!map || !pos || !out || count < 0) return NPP_ERR_INVALID;
+    ReachBuilt R;
+    std::string err;
+    if (!build_reach(map, n, R, err)) return NPP_ERR_INVALID;
+    ReachHdr H;
+    std::vector<unsigned char> blob;
+    pack_reach(R, H, blob);
+    ReachTabs T{&H, blob.data() + H.base};
+    std::vector<uint32_t> stamp(REACH_CELLS, 0u);
+    std::vector<double> raw(REACH_CELLS, 0.0);
+    ReachMiss M{stamp.data(), raw.data(), 1u};
+    for (int k = 0; k < count; k++) {
+        if (new_episode && new_episode[k]) M.epoch++;   // clear_cache() of the path calculator (reachability_mixin.py:67-70)
+        const int st = reach_features(T, pos[2 * k], pos[2 * k + 1], mines ? mines[2 * k] : H.n_mines, mines ? mines[2 * k + 1] : 0,
+                                      out + (size_t)k * REACH_DIM, nullptr, &M);
+        if (status) status[k] = st | (H.supported ? 0 : 2);
+        if (raw_out) {   // the dictionary entry of the ninja's cell after this query (NaN = none)
+            int cx = reach_cell24(pos[2 * k]), cy = reach_cell24(pos[2 * k + 1]);
+            cx = cx < 0 ? 0 : (cx > 43 ? 43 : cx);
+            cy = cy < 0 ? 0 : (cy > 24 ? 24 : cy);
+            raw_out[k] = stamp[cx * 25 + cy] == M.epoch ? raw[cx * 25 + cy] : NAN;
+        }
     }
     return NPP_OK;
 }

@@ -14,7 +14,7 @@
 #pragma once
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NPP_HD __host__ __device__
 #else
 #define NPP_HD
@@ -26,6 +26,8 @@ namespace npp {
 constexpr int RW = 84, RH = 46, RNODES = RW * RH;   // 3864
 constexpr int SDF_W = 88, SDF_H = 50;                // mine SDF grid, 12-px cells over the 1056 x 600 world
 constexpr int REACH_DIM = 38;
+constexpr int REACH_MAX_CAND = 16;                   // goal nodes the miss branch can select for one goal
+constexpr int REACH_CELLS = 44 * 25;                 // 24-px cells: keys of the calculator's per-episode (start cell, goal cell) cache
 
 // Per-level tables as laid out in HBM (one ReachHdr per level + a blob; offsets in bytes from `base` in the blob).
 struct ReachHdr {
@@ -50,6 +52,16 @@ struct ReachHdr {
     int32_t n_mines;                   // toggle mines of both types
     uint32_t n_words;                  // entity-state words of the level
     uint32_t off_mine_mask;            // u32[n_words]: bit 2k of word w set when entity 16 w + k is a toggle mine
+    // ---- the cache-miss branch of get_distance for the exit door (path_distance_calculator.py:1218-1485), taken on EVERY query when
+    //      the door lies within 24 px of its switch but not within 12: goal-id inference says "switch", validation against the
+    //      switch's cached position fails.  Static per level: the goal node as a function of the temp start node, and the physics
+    //      A* cost (path_distance_calculator.py:744-845) from every start node to that goal node.
+    uint32_t miss_exit;                // 1: exit-door queries take the miss branch
+    uint32_t n_cand;                   // goal nodes find_goal_node_closest_to_start can return for the exit door
+    int32_t cand[REACH_MAX_CAND];      // their node ids
+    uint32_t off_cgoal;                // u8 [RNODES] index into cand[] for a temp start node, 0xff = none
+    uint32_t off_astar;                // f64[n_cand][RNODES] raw A* cost start node -> cand[k]; NaN = pair not tabulated
+    uint32_t sw_alias;                 // 1: switch and door share a 24-px cell, i.e. one key of the per-episode cache
     uint32_t pad_;
     uint64_t base;                     // byte offset of this level's tables in the blob of all levels
 };

@@ -20,6 +20,9 @@ struct ReachBuilt {
     std::vector<double> mh[2];                // [RNODES][2]
     std::vector<float> sdf, grad;             // empty when the level has no mines
     std::vector<uint32_t> mine_mask;          // per entity-state word: bit 2k set when entity 16 w + k is a toggle mine
+    std::vector<double> mine_mult;            // [RNODES] MineProximityCostCache multiplier of the adjacency nodes (1.0 = none)
+    std::vector<uint8_t> cgoal;               // [RNODES] miss branch: index into hdr.cand for a temp start node (0xff = none)
+    std::vector<double> astar;                // [n_cand][RNODES] miss branch: physics A* cost to hdr.cand[k] (NaN = not tabulated)
     bool has_sdf = false;
     int surface_area = 0;                     // node count of the area-scale flood fill (0 = it failed)
     std::string note;                         // why hdr.supported == 0

@@ -15,8 +15,11 @@
 //   * the directional platform ray cast snaps to multiples of 12 while nodes sit at 6 mod 12: it never finds a node and
 //     features 30-37 are 1.0;
 //   * features 18-19 (mine gradient) look the SDF up on the wrong object and stay 0.
-// Not restated: the cache-miss branch (physics-aware A*, path_distance_calculator.py:1230-1485), taken when the ninja has no
-// node with a cached distance; `status` bit 0 reports it and the distances are treated as unreachable.
+// The cache-miss branch of get_distance (path_distance_calculator.py:949-960, 1218-1485) is restated for the exit door of the levels
+// whose door lies within 24 px of its switch (ReachHdr::miss_exit: every exit query misses there): node selection here, the
+// physics A* cost from the per-level table the host builds (npp_reach.cpp), and the calculator's per-episode
+// (start cell, goal cell) -> cost dictionary as a per-env array (ReachMiss).  Elsewhere a miss (the ninja has no node with a cached
+// distance) is reported through `status` bit 0 and the distance is treated as unreachable.
 #pragma once
 #include <cmath>
 
@@ -24,9 +27,30 @@
 
 namespace npp {
 
+// Per-env view of CachedPathDistanceCalculator.cache: key (start 24-px cell, goal 24-px cell) -> raw A* cost, filled on a miss,
+// consulted BEFORE the level cache (path_distance_calculator.py:949-960), emptied by clear_cache() at every episode reset
+// (reachability_mixin.py:67-70).  stamp[cell] == epoch marks a live entry; a new episode bumps the epoch.  One goal cell is
+// tracked: the exit door's (the switch shares the entries when it lies in the same cell, ReachHdr::sw_alias).  Capacity: the
+// calculator holds 5000 entries (max(max_cache_size, 5000)), a level has 1100 cells, so nothing is ever evicted.
+struct ReachMiss {
+    uint32_t *stamp;   // [REACH_CELLS]
+    double *raw;       // [REACH_CELLS]
+    uint32_t epoch;    // never 0
+};
+
+// int(v // 24) (Python float floor division is exact; the quotient of the division below can be off by one ulp)
+NPP_HD inline int reach_cell24(double v) {
+    int c = (int)floor(v / 24.0);
+    if ((double)c * 24.0 > v) c--;
+    if ((double)(c + 1) * 24.0 <= v) c++;
+    return c;
+}
+
 struct ReachTabs {
     const ReachHdr *H;
     const unsigned char *blob;
+    NPP_HD const unsigned char *cgoal() const { return blob + H->off_cgoal; }
+    NPP_HD const double *astar(int k) const { return reinterpret_cast<const double *>(blob + H->off_astar) + (long)k * RNODES; }
     NPP_HD const unsigned char *in() const { return blob + H->off_in; }
     NPP_HD const double *dist(int g) const { return reinterpret_cast<const double *>(blob + H->off_dist) + (long)g * RNODES; }
     NPP_HD const int16_t *hop(int g) const { return reinterpret_cast<const int16_t *>(blob + H->off_hop) + (long)g * RNODES; }
@@ -44,7 +68,8 @@ NPP_HD inline int reach_order_key(int id) {
 NPP_HD inline double reach_floor(double v) { return floor(v); }
 
 // find_ninja_node (pathfinding_utils.py:1331-1497).  goal_node < 0: no goal node given (closest overlapping node wins);
-// otherwise the overlapping node with the smallest cached distance to goal `g` wins (Euclidean to goal_node when not cached).
+// otherwise the overlapping node with the smallest cached distance to goal `g` wins (Euclidean to goal_node when not cached,
+// or always when g < 0: the call carries no goal id).
 NPP_HD inline int reach_find_ninja_node(const ReachTabs &T, double px, double py, int goal_node, int g) {
     const double nx = px - 24.0, ny = py - 24.0;
     const unsigned char *in = T.in();
@@ -72,7 +97,7 @@ NPP_HD inline int reach_find_ninja_node(const ReachTabs &T, double px, double py
             double bd = INFINITY;
             const double gx = reach_node_x(goal_node), gy = reach_node_y(goal_node);
             for (int k = 0; k < nc; k++) {
-                double d = T.dist(g)[cand[k]];
+                double d = g >= 0 ? T.dist(g)[cand[k]] : INFINITY;   // g < 0: no goal id -> Euclidean (the miss branch)
                 if (d == INFINITY) {
                     const double ex = gx - reach_node_x(cand[k]), ey = gy - reach_node_y(cand[k]);
                     d = sqrt(ex * ex + ey * ey);   // ((gx - nx) ** 2 + (gy - ny) ** 2) ** 0.5 on integers
@@ -104,15 +129,71 @@ NPP_HD inline int reach_find_ninja_node(const ReachTabs &T, double px, double py
     return best;
 }
 
+// find_ninja_node with search_radius_override = R, or (R < 0) the "ANY closest node in the entire adjacency graph" loop that
+// follows the ladder in get_distance's miss branch: a linear scan in dict order.  goal_node >= 0 with more than one node in range:
+// the node closest to the goal node wins (Euclidean; first minimum in dict order), otherwise the one closest to the ninja.
+NPP_HD inline int reach_scan_node(const ReachTabs &T, double px, double py, double R, int goal_node) {
+    const double nx = px - 24.0, ny = py - 24.0;
+    const unsigned char *in = T.in();
+    int best = -1, bkey = 0, count = 0, gbest = -1, gkey = 0;
+    double bd = 0.0;
+    long gd = 0;
+    for (int id = 0; id < RNODES; id++) {
+        if (!in[id]) continue;
+        const double dx = reach_node_x(id) - nx, dy = reach_node_y(id) - ny, d2 = dx * dx + dy * dy;
+        if (R >= 0.0 && !(d2 <= R * R)) continue;
+        const int key = reach_order_key(id);
+        count++;
+        if (best < 0 || d2 < bd || (d2 == bd && key < bkey)) { best = id; bd = d2; bkey = key; }
+        if (goal_node >= 0) {
+            const long ex = reach_node_x(goal_node) - reach_node_x(id), ey = reach_node_y(goal_node) - reach_node_y(id), e2 = ex * ex + ey * ey;
+            if (gbest < 0 || e2 < gd || (e2 == gd && key < gkey)) { gbest = id; gd = e2; gkey = key; }
+        }
+    }
+    return (goal_node >= 0 && count > 1 && R >= 0.0) ? gbest : best;
+}
+
+// The miss branch for the exit door (path_distance_calculator.py:949-960 and 1218-1485): the raw cost of the calculator's
+// per-episode dictionary for the ninja's cell, computed and stored on the first query of the cell.  `peek`: look the entry up
+// without creating it (the switch's query, which only ever READS the shared key); returns NaN when absent.
+NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, double px, double py, ReachMiss *M, bool peek, bool *miss) {
+    int cx = reach_cell24(px), cy = reach_cell24(py);
+    cx = cx < 0 ? 0 : (cx > 43 ? 43 : cx);
+    cy = cy < 0 ? 0 : (cy > 24 ? 24 : cy);
+    const int cell = cx * 25 + cy;
+    if (M && M->stamp[cell] == M->epoch) return M->raw[cell];
+    if (peek) return NAN;
+    // temp start node: find_ninja_node, then the 48 / 150 px retries, then any closest node
+    int t = reach_find_ninja_node(T, px, py, -1, 0);
+    if (t < 0) t = reach_scan_node(T, px, py, 48.0, -1);
+    if (t < 0) t = reach_scan_node(T, px, py, 150.0, -1);
+    if (t < 0) t = reach_scan_node(T, px, py, -1.0, -1);
+    double raw = INFINITY;
+    if (t >= 0) {
+        const int k = T.cgoal()[t];
+        if (k < (int)T.H->n_cand) {
+            const int c = T.H->cand[k];
+            // the final start node: get_distance still carries the INFERRED goal id ("switch") at this point, so among several overlapping
+            // nodes the one with the smallest cached distance to the switch wins (Euclidean to the goal node when it has none)
+            int s = reach_find_ninja_node(T, px, py, c, 0);
+            if (s < 0) s = reach_scan_node(T, px, py, 48.0, c);
+            if (s < 0) s = reach_scan_node(T, px, py, 150.0, c);
+            if (s < 0) s = reach_scan_node(T, px, py, -1.0, c);
+            if (s >= 0) {
+                raw = T.astar(k)[s];
+                if (raw != raw) { raw = INFINITY; *miss = true; }   // pair outside the tabulated neighbourhood
+            }
+        } else *miss = true;
+    }
+    if (M) { M->stamp[cell] = M->epoch; M->raw[cell] = raw; }
+    return raw;
+}
+
 // get_distance / get_geometric_distance on the level-cache path (they return the same number there).  g: 0 exit switch,
 // 1 exit door.  Returns +inf when unreachable; sets *miss when the reference would leave the level-cache path.
-NPP_HD inline double reach_goal_distance(const ReachTabs &T, double px, double py, int g, double entity_radius, bool *miss) {
+NPP_HD inline double reach_level_distance(const ReachTabs &T, double px, double py, int g, double entity_radius, bool *miss) {
     const ReachHdr &H = *T.H;
-    const int gx = H.goal_x[g], gy = H.goal_y[g];
-    if (gx == 0 && gy == 0) return INFINITY;
     const double combined = 10.0 + entity_radius;
-    const double dx = px - gx, dy = py - gy;
-    if (dx * dx + dy * dy <= combined * combined) return 0.0;
     const int gid = g == 1 ? H.exit_gid : 0;   // which goal's tables the reference reads (goal-id inference, see ReachHdr)
     const int sn = reach_find_ninja_node(T, px, py, H.goal_node[2 + g], gid);   // goal node of get_distance: thresholds 16 / 22, then 32
     if (sn < 0) { *miss = true; return INFINITY; }
@@ -133,24 +214,49 @@ NPP_HD inline double reach_goal_distance(const ReachTabs &T, double px, double p
     return t > 0.0 ? t : 0.0;
 }
 
+// get_distance (path_distance_calculator.py:847-1485).  g: 0 exit switch, 1 exit door.  Returns +inf when unreachable; sets *miss
+// when the reference would run a part of its miss branch that is not tabulated.  geometric = true: get_geometric_distance
+// (path_distance_calculator.py:1487-1975), which never looks at the per-episode dictionary.
+NPP_HD inline double reach_goal_distance(const ReachTabs &T, double px, double py, int g, double entity_radius, ReachMiss *M, bool geometric,
+                                         bool *miss) {
+    const ReachHdr &H = *T.H;
+    const int gx = H.goal_x[g], gy = H.goal_y[g];
+    if (gx == 0 && gy == 0) return INFINITY;
+    const double combined = 10.0 + entity_radius;
+    const double dx = px - gx, dy = py - gy;
+    if (dx * dx + dy * dy <= combined * combined) return 0.0;
+    if (H.miss_exit && !geometric) {
+        // the per-episode dictionary comes first; its key holds the goal's CELL, so a switch in the door's cell reads the door's entry
+        if (g == 1 || H.sw_alias) {
+            const double raw = reach_exit_miss_raw(T, px, py, M, g == 0, miss);
+            if (raw == raw) {
+                const double t = raw - combined;
+                return t > 0.0 ? t : 0.0;   // max(0.0, inf - r) = inf
+            }
+        }
+    }
+    return reach_level_distance(T, px, py, g, entity_radius, miss);
+}
+
 NPP_HD inline float reach_clip01(double v) { return (float)(v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v)); }
 
 // out[38]; sdf_out[3] = mine_sdf_features (value, gradient) at the ninja (npp_environment.py mine_sdf_features);
 // returns status: bit 0 = the reference would have run its physics A* fallback here (not restated)
-NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int total_mines, int deadly_mines, float *out, float *sdf_out) {
+NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int total_mines, int deadly_mines, float *out, float *sdf_out,
+                                 ReachMiss *M = nullptr) {
     const ReachHdr &H = *T.H;
     for (int k = 0; k < REACH_DIM; k++) out[k] = 0.f;
     bool miss = false;
     out[0] = H.f0;
     const double area = H.area_scale;
     double d_sw = INFINITY, d_ex = INFINITY;
-    if (H.sw_valid) d_sw = reach_goal_distance(T, px, py, 0, 6.0, &miss);
+    if (H.sw_valid) d_sw = reach_goal_distance(T, px, py, 0, 6.0, M, false, &miss);
     if (d_sw != INFINITY) out[1] = reach_clip01(1.0 - d_sw / area);
     else if (H.ex_valid) {   // third priority of the "next objective" ladder: the exit door (no locked-door switches reach here)
-        const double d = reach_goal_distance(T, px, py, 1, 12.0, &miss);
+        const double d = reach_goal_distance(T, px, py, 1, 12.0, M, false, &miss);
         if (d != INFINITY) out[1] = reach_clip01(1.0 - d / area);
     }
-    if (H.ex_valid) d_ex = reach_goal_distance(T, px, py, 1, 12.0, &miss);
+    if (H.ex_valid) d_ex = reach_goal_distance(T, px, py, 1, 12.0, M, false, &miss);
     if (d_ex != INFINITY) out[2] = reach_clip01(1.0 - d_ex / area);
     out[3] = H.exit_reachable;
     out[4] = d_sw != INFINITY ? reach_clip01(d_sw / area) : 1.f;
@@ -199,9 +305,10 @@ NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int t
             if (al < -0.3) out[20] = 1.f;
         }
     }
-    if (sw_dir && d_sw != INFINITY) {   // 21: log-normalised physics cost / geometric distance (both are the cached geometric one)
-        const double geo = d_sw;
-        if (geo > 0.001) {
+    if (sw_dir) {   // 21: log-normalised physics cost / geometric distance.  Both come from the level cache's geometric table (ratio 1 ->
+                    // 1/3) unless the switch query was answered from the per-episode dictionary (ReachHdr::sw_alias)
+        const double geo = (H.miss_exit && H.sw_alias) ? reach_goal_distance(T, px, py, 0, 6.0, M, true, &miss) : d_sw;
+        if (geo != INFINITY && geo > 0.001) {
             double ratio = d_sw / geo;
             ratio = ratio > 0.1 ? ratio : 0.1;
             out[21] = reach_clip01((log(ratio) + 2.0) / 6.0);

@@ -13,16 +13,8 @@
 namespace npp {
 namespace {
 
-// int(v // 24) for v >= 0 (Python float floor division is exact; the quotient of the division below can be off by one ulp)
-__device__ inline int cell24(double v) {
-    int c = (int)floor(v / 24.0);
-    if ((double)c * 24.0 > v) c--;
-    if ((double)(c + 1) * 24.0 <= v) c++;
-    return c;
-}
-
 __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key,
-                                                       float *cache, float *out, float *sdf_out, int32_t *status) {
+                                                       float *cache, ReachMissDev md, float *out, float *sdf_out, int32_t *status) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= a.n) return;
     const int lvl = a.env_level[env];
@@ -33,11 +25,27 @@ __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const Reach
     // exit_switch_activated (nplay_headless.py:566-576): not switch.active
     bool sw = true;
     if (L.obs_switch >= 0) sw = ((a.ent_bits[(size_t)(L.obs_switch >> 4) * a.n + env] >> ((L.obs_switch & 15) * 2)) & 3u) == 0;
-    const int cx = cell24(px), cy = cell24(py);
+    const int cx = reach_cell24(px), cy = reach_cell24(py);
     const uint32_t k = 0x80000000u | ((uint32_t)(cx & 0x3fff)) | ((uint32_t)(cy & 0x3fff) << 14) | ((uint32_t)sw << 28);
     float *c = cache + (size_t)env * (REACH_DIM + 1);
     float f[REACH_DIM], sd[3];
     int st = 0;
+    // per-episode dictionary of the path calculator (ReachMiss): a reset of the env since the last call empties it.  The episode
+    // counter lives in state word E (npp_kernels.hip: Nj::fastord bits 2-14)
+    ReachMiss M{nullptr, nullptr, 1u};
+    if (md.stamp) {
+        const uint32_t ep = (a.u32[(size_t)U_E * a.n + env] >> 19) & 0x1fffu;
+        uint32_t epoch = md.epoch[env];   // 0 = never called (stamps are 0 too: nothing may match)
+        if (epoch == 0u || md.last_episode[env] != ep) {
+            epoch++;
+            if (epoch == 0u) epoch = 1u;
+            md.epoch[env] = epoch;
+            md.last_episode[env] = ep;
+        }
+        M.stamp = md.stamp + (size_t)env * REACH_CELLS;
+        M.raw = md.raw + (size_t)env * REACH_CELLS;
+        M.epoch = epoch;
+    }
     if (key[env] == k) {
 #pragma unroll
         for (int i = 0; i < REACH_DIM; i++) f[i] = c[i];
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const Reach
                 const uint32_t b = a.ent_bits[(size_t)w * a.n + env];
                 deadly += __popc(~(b | (b >> 1)) & m);
             }
-        st = reach_features(T, px, py, H.n_mines, deadly, f, sd);
+        st = reach_features(T, px, py, H.n_mines, deadly, f, sd, M.stamp ? &M : nullptr);
 #pragma unroll
         for (int i = 0; i < REACH_DIM; i++) c[i] = f[i];
         c[REACH_DIM] = (float)st;
@@ -79,10 +87,13 @@ __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const Reach
 }
 
 __global__ __launch_bounds__(256) void npp_reach_restore_kernel(KernelArgs a, const uint32_t *src_key, const float *src_cache,
-                                                                uint32_t *key, float *cache) {
+                                                                uint32_t *key, float *cache, ReachMissDev md) {
     const int env = blockIdx.x * 256 + threadIdx.x;
     if (env >= a.n) return;
     if (a.reset_mask && !a.reset_mask[env]) return;
+    // a restored checkpoint is "reset + replay of the action sequence" in the reference (base_environment.py:1769-1789): the path
+    // calculator's dictionary is empty afterwards; a newly assigned level starts empty as well
+    if (md.stamp) md.last_episode[env] = 0xffffffffu;
     if (!src_key) { key[env] = 0u; return; }
     key[env] = src_key[env];
     for (int i = 0; i <= REACH_DIM; i++) cache[(size_t)env * (REACH_DIM + 1) + i] = src_cache[(size_t)env * (REACH_DIM + 1) + i];
@@ -91,14 +102,14 @@ __global__ __launch_bounds__(256) void npp_reach_restore_kernel(KernelArgs a, co
 }  // namespace
 
 hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, const float *src_cache, uint32_t *key, float *cache,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(npp_reach_restore_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a, src_key, src_cache, key, cache);
+                                const ReachMissDev &md, hipStream_t s) {
+    hipLaunchKernelGGL(npp_reach_restore_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a, src_key, src_cache, key, cache, md);
     return hipGetLastError();
 }
 
-hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key, float *cache, float *out,
-                        float *sdf_out, int32_t *status, hipStream_t s) {
-    hipLaunchKernelGGL(npp_reach_kernel, dim3((a.n + 63) / 64), dim3(64), 0, s, a, rh, rblob, key, cache, out, sdf_out, status);
+hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key, float *cache,
+                        const ReachMissDev &md, float *out, float *sdf_out, int32_t *status, hipStream_t s) {
+    hipLaunchKernelGGL(npp_reach_kernel, dim3((a.n + 63) / 64), dim3(64), 0, s, a, rh, rblob, key, cache, md, out, sdf_out, status);
     return hipGetLastError();
 }
 

@@ -315,10 +315,14 @@ def test_fast_reset_vs_reference_fixtures(golden):
     assert checked == sum(steps)
 
 
-def test_fast_reset_autoreset_vs_oracle(oracle_mod):
-    """In-kernel auto-reset under NPP_FLAG_FAST_RESET (what NppVecEnvironment uses by default) on zoo, mine and door levels:
-    bit-identical to the oracle stepping the same actions with fast_reset() after every terminal step; and different from
-    the full-reset handle on the zoo levels (movers keep going)."""
+@pytest.mark.parametrize("explicit_first_reset", [True, False])
+def test_fast_reset_autoreset_vs_oracle(oracle_mod, explicit_first_reset):
+    """In-kernel auto-reset under NPP_FLAG_FAST_RESET (what NppVecEnvironment uses by default) on zoo, mine and door levels, in
+    the reference env's own sequence: load_map at construction (base_environment.py:318), the FIRST reset() reloads
+    the map = Simulator.reset (npp_environment.py:518-557, _last_reset_map_name is None), every later same-level reset is
+    Simulator.fast_reset.  explicit_first_reset=True: npp_reset (mode 0) plays that first reset() and every auto-reset is fast;
+    False: nobody calls reset, so the first AUTO-reset of each env is the full one.  Bit-identical to the oracle doing
+    load -> reset() -> ... -> fast_reset(); and different from the full-reset handle on the zoo levels (movers keep going)."""
     from nclone_amd.engine import NppBatch
     from nclone_amd.levels import door_levels, mine_levels, zoo_levels
 
@@ -333,6 +337,8 @@ def test_fast_reset_autoreset_vs_oracle(oracle_mod):
         b = NppBatch(n, autoreset=True, fast_reset=fast)
         b.load_levels(levels)
         b.assign_levels(lvl)
+        if explicit_first_reset:
+            b.reset()
         b.set_truncation_limit(150)          # forces resets mid-flight on top of deaths
         for s in range(steps):
             b.step(d_acts[s])
@@ -345,10 +351,18 @@ def test_fast_reset_autoreset_vs_oracle(oracle_mod):
     for e in range(n):
         o = oracle_mod.Oracle("mul")
         o.load(levels[lvl[e]])
+        had_full = False
+        if explicit_first_reset:
+            o.reset()
+            had_full = True
         for s in range(steps):
             k, fl = o.env_step(int(acts[s, e]), 4)
             if fl or o.frame >= 150:
-                o.fast_reset()
+                if had_full:
+                    o.fast_reset()
+                else:
+                    o.reset()
+                    had_full = True
                 resets += 1
         of, od = o.core()
         assert np.array_equal(f[e], of), (e, lvl[e], f[e], of)

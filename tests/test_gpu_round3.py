@@ -1,0 +1,203 @@
+"""Round-3 GPU tests: BASELINE config 5 as a whole (the full Dict step at 8192 envs on ALL 21 door levels, including the one
+whose reachability goes through the reference's physics A*), the bench line's other_configs / config4 blocks, the dynamic
+truncation limit, and the Gymnasium surface's checkpoint option."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 8192
+FULL = ("positions", "spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features",
+        "reach_status")
+
+
+def test_config5_full_dict_step_on_the_whole_door_set(oracle_mod):
+    """BASELINE config 5: 8192 envs, curriculum 4 (locked doors / switches), every Dict observation every step, on the whole
+    21-level door set (round 2 dropped `hcorr:door:100053`, whose exit door sits 18 px from its switch).  Checked:
+      * every output of the block is identical between the two replicas of each 32-env group (no env leaks into another);
+      * physics + game_state of a 96-env sample against the CPU oracle in the env's reset sequence (load, reset(), fast_reset());
+      * reachability_features of a sample that covers every level -- incl. the A* level -- against the HOST build of the same
+        function driven by the recorded positions / episode boundaries (cache rule, per-episode dictionary, live mine counts);
+      * player_frame = the reference's axis-swapped crop of the whole rendered frame, global_view = OpenCV-order area reduction of
+        the whole frame, for sampled envs; switch_states against the entity dump."""
+    from nclone_amd import _native as nat
+    from nclone_amd.engine import NppBatch, compile_level_entities, reach_level_info
+    from nclone_amd.levels import door_levels
+    from tests.test_gpu_render import _area_tabs, _reduce_frame
+
+    levels, tags = door_levels()
+    assert len(levels) == 21 and all(reach_level_info(m)["supported"] for m in levels)
+    lib = nat.lib()
+    level_ids = (np.arange(N) // 64) % len(levels)
+    steps = 48
+    acts_np = np.random.default_rng(33).integers(0, 6, size=(steps, N)).astype(np.uint8).reshape(steps, N // 64, 64)
+    acts_np[:, :, 32:] = acts_np[:, :, :32]
+    acts_np = acts_np.reshape(steps, N)
+    acts = torch.from_numpy(acts_np).cuda()
+    b = NppBatch(N, autoreset=True, fast_reset=True, outputs=FULL)
+    b.load_levels(levels)
+    b.assign_levels(level_ids)
+    b.reset()                      # the env's first reset(): Simulator.reset
+    b.set_truncation_limit(120)    # episodes end inside the run on every level
+    # sample: 3 envs of every level (first block of the level) + extra envs of the A* level
+    first_block = {li: int(np.flatnonzero(level_ids == li)[0]) for li in range(len(levels))}
+    astar = tags.index("hcorr:door:100053")
+    sample = sorted({first_block[li] + k for li in range(len(levels)) for k in (0, 7, 19)} |
+                    {int(e) for e in np.flatnonzero(level_ids == astar)[:24]})
+    sample = np.array(sample)
+    hist_pos, hist_flags, hist_feat = [], [], []
+
+    def observe_all():
+        b.switch_states()
+        b.render_player_frame()
+        b.render_global_view()
+        b.reachability()
+
+    b.observe()
+    observe_all()
+    h = b.to_host(("positions", "reachability_features", "reach_status", "flags"))
+    assert not h["reach_status"].any()
+    hist_pos.append(h["positions"][sample, :2].copy())
+    hist_flags.append(np.zeros(len(sample), np.uint8))
+    hist_feat.append(h["reachability_features"][sample].copy())
+    for t in range(steps):
+        b.step(acts[t])
+        observe_all()
+        h = b.to_host(("positions", "reachability_features", "reach_status", "flags"))
+        assert not h["reach_status"].any(), t
+        hist_pos.append(h["positions"][sample, :2].copy())
+        hist_flags.append(h["flags"][sample].copy())
+        hist_feat.append(h["reachability_features"][sample].copy())
+    out = {k: v.copy() for k, v in b.to_host().items()}
+    f, di = b.dump_state()
+    # ---- replicas
+    for k, v in out.items():
+        if k in ("work",):
+            continue
+        blk = v.reshape((N // 64, 64) + v.shape[1:])
+        assert np.array_equal(blk[:, :32], blk[:, 32:]), k
+    assert out["player_frame"].std() > 10 and out["global_view"].std() > 10
+    # ---- physics of a sample vs the oracle
+    for e in np.random.default_rng(4).choice(N, size=96, replace=False):
+        o = oracle_mod.Oracle("mul")
+        assert o.load(levels[level_ids[e]]) == 0
+        o.reset()
+        for t in range(steps):
+            k, fl = o.env_step(int(acts_np[t, e]), 4)
+            if fl or o.frame >= 120:
+                o.fast_reset()
+        of, od = o.core()
+        assert np.array_equal(f[e], of), (tags[level_ids[e]], e)
+        assert np.array_equal(di[e, :22], od[:22]), (tags[level_ids[e]], e)
+        assert np.abs(out["game_state"][e, :40] - o.ninja_state().astype(np.float32)).max() <= 2e-6
+    # ---- reachability of the sample vs the host build of the same function along the recorded rollout
+    P = np.stack(hist_pos, axis=1)          # [sample, steps + 1, 2]
+    FL = np.stack(hist_flags, axis=1)
+    RF = np.stack(hist_feat, axis=1)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    recomputed = astar_rows = 0
+    for si, e in enumerate(sample):
+        m = np.ascontiguousarray(levels[level_ids[e]])
+        ents = compile_level_entities(m)
+        total = int((ents[:, 0] == 1).sum())
+        key, rows, pending = None, [], 1
+        for t in range(steps + 1):
+            fl = int(FL[si, t])
+            ended = (fl & 11) != 0                                  # won / dead / truncated: the env was reset inside the step
+            if ended:
+                pending = 1
+            sw = ((fl & 4) != 0) and not ended
+            k = (int(P[si, t, 0] // 24), int(P[si, t, 1] // 24), sw)
+            if k != key:
+                key = k
+                rows.append((t, pending))
+                pending = 0
+        ts = np.array([r[0] for r in rows])
+        pos = np.ascontiguousarray(P[si, ts])
+        ne = np.array([r[1] for r in rows], dtype=np.uint8)
+        deadly = np.rint(RF[si, ts, 11].astype(np.float64) * total).astype(np.int32)
+        mines = np.ascontiguousarray(np.stack([np.full(len(ts), total, np.int32), deadly], axis=1))
+        exp = np.zeros((len(ts), 38), np.float32)
+        st = np.zeros(len(ts), np.int32)
+        assert lib.npp_reach_rollout_host(m.ctypes.data_as(C.POINTER(C.c_double)), m.size, p(pos), p(mines), p(ne), len(ts), p(exp), p(st),
+                                          None) == 0
+        assert not st.any()
+        cur = 0
+        for t in range(steps + 1):
+            while cur + 1 < len(ts) and ts[cur + 1] <= t:
+                cur += 1
+            assert np.array_equal(RF[si, t], exp[cur]), (tags[level_ids[e]], int(e), t)
+        recomputed += len(ts)
+        astar_rows += len(ts) if level_ids[e] == astar else 0
+    assert recomputed > 4 * len(sample) and astar_rows > 50
+    # ---- frames of sampled envs: crop / reduction of the whole rendered frame
+    xtab, ytab = _area_tabs(100, 1056.0 / 100, 1056), _area_tabs(176, 600.0 / 176, 600)
+    gv = b.out.t["global_view"]
+    for e in sample[::9]:
+        full_t = b.render_frame(int(e), 1)[0, :, :, 0]
+        assert torch.equal(gv[int(e), :, :, 0], _reduce_frame(full_t.float(), xtab, ytab)), int(e)
+        full = full_t.cpu().numpy()
+        px, py = out["positions"][e, 0], out["positions"][e, 1]
+        r0, r1, c0, c1 = max(0, int(px - 42)), min(600, int(px + 42)), max(0, int(py - 42)), min(1056, int(py + 42))   # the axis swap
+        hh, ww = max(0, r1 - r0), max(0, c1 - c0)
+        ref = np.zeros((84, 84), np.uint8)
+        if hh and ww:
+            ref[(84 - hh) // 2:(84 - hh) // 2 + hh, (84 - ww) // 2:(84 - ww) // 2 + ww] = full[r0:r1, c0:c1]
+        assert np.array_equal(out["player_frame"][e, :, :, 0], ref), int(e)
+    # ---- switch_states: collected flags follow the entity states
+    for e in sample[::5]:
+        ents = compile_level_entities(levels[level_ids[e]])
+        st_e = b.dump_entities(int(e))
+        locked = np.flatnonzero(ents[:, 0] == 6)[:5]
+        ss = out["switch_states"][e].reshape(5, 5)
+        for j, slot in enumerate(locked):
+            x, y = np.float32(np.clip(ents[slot, 1] / 1056.0, 0.0, 1.0)), np.float32(np.clip(ents[slot, 2] / 600.0, 0.0, 1.0))
+            assert np.array_equal(ss[j], np.array([x, y, x, y, 0.0 if (st_e[slot] & 1) else 1.0], np.float32)), (int(e), j)
+        assert not ss[len(locked):].any()
+    b.close()
+
+
+def test_bench_default_line_carries_the_other_configs():
+    """`python bench.py` (N = 1, no --workload): value = config 2 and other_configs = configs 3, 4-shard and 5 with their own
+    rooflines; config 5 runs on its whole level set."""
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--preroll", "40", "--envs-per-gpu",
+                        "1024", "--other-steps", "12", "--no-cpu-baseline", "--async-streams", "0", "--open-loop-chunk", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 30 and line["value"] > 0 and "config 2" in line["config"]["workload"]
+    oc = line["other_configs"]
+    assert set(oc) == {"config3", "config4_shard", "config5_full_obs"}
+    for k, blk in oc.items():
+        assert blk["value"] > 0 and blk["steps"] == 12 and blk["roofline"]["frac"] > 0, k
+    assert oc["config3"]["roofline_render"]["kernel"] == "npp_render_kernel" and oc["config3"]["roofline_render"]["frac"] > 0
+    c5 = oc["config5_full_obs"]
+    assert "0 level(s) dropped" in c5["config"]["workload"] and "21 levels" in c5["config"]["workload"]
+    assert c5["roofline_global_view"]["frac"] > 0 and c5["roofline_reach"]["frac"] > 0
+    assert set(c5["obs_kernels"]) >= {"switch_states", "player_frame", "global_view", "reachability"}
+
+
+def test_bench_two_ranks_default_line_reports_config4():
+    """`python bench.py --gpus 2` without --workload (what a SCALE run launches): value = config 2 on both ranks and a `config4`
+    block = the mixed set with and without the observation gather.  Rehearsed on one GPU over gloo."""
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--steps", "20",
+                        "--warmup", "5", "--preroll", "10", "--envs-per-gpu", "1024", "--other-steps", "10", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and "config 2" in line["config"]["workload"] and line["value"] > 0
+    c4 = line["config4"]
+    assert "config 4" in c4["config"]["workload"] and c4["value"] > 0
+    assert c4["with_obs_gather"]["own_shard_roundtrip_ok"] and c4["with_obs_gather"]["value"] > 0
