@@ -126,6 +126,16 @@ int npp_reset_ex(npp_handle h, const uint8_t *env_mask, int mode);
 
 /* Truncation limit in frames (truncation_checker.py:21-29); limits == NULL sets `all` for every env. */
 int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all);
+/* The reference env's DYNAMIC limit (npp_environment.py:1238-1256, base_environment.py:1078-1100 ->
+ * truncation_calculator.py:19-57): per level int(clip(sqrt(reachable surface area) * 20 * 25, 1200, 10000)), the surface area
+ * being the node count the reachability graph's flood fill finds from the spawn (npp_reach.cpp, pinned by the reference's own
+ * values in tests/golden/reach.npz).  enable != 0: every env takes its level's limit now and again at every npp_load_levels /
+ * npp_assign_levels (for the envs assigned); it drives both the truncation flag and game_state[40] (time_remaining).  A later
+ * npp_set_truncation_limit overrides it until the next assignment.  Known deviation: the reference holds the 10 000-frame
+ * fallback until its first reward calculation after a level load, i.e. for the first step's observation. */
+int npp_set_dynamic_truncation(npp_handle h, int enable);
+/* Host-only: that limit and the surface area for one level. */
+int npp_level_truncation_limit(const double *map, int64_t n, int32_t *limit, int32_t *surface_area);
 
 /* NppEnvironment.step for all envs (base_environment.py:483-755): d_actions[N] in 0..5
  * (_actions_to_execute, :366-402), up to frame_skip ticks with early stop on win/death (:535-609),

@@ -28,7 +28,7 @@ EXPORTS = [
     "npp_render_player_frame", "npp_dump_state", "npp_dump_entities", "npp_dump_level_segments",
     "npp_compile_level_segments", "npp_compile_level_entities", "npp_set_step_variant", "npp_get_step_variant", "npp_num_envs", "npp_num_levels",
     "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many", "npp_render_frame", "npp_plan_zoo_block", "npp_reset_ex",
-    "npp_reachability", "npp_reach_compile", "npp_reach_features_host", "npp_reach_compile_miss", "npp_reach_rollout_host",
+    "npp_reachability", "npp_reach_compile", "npp_reach_features_host", "npp_reach_compile_miss", "npp_reach_rollout_host", "npp_set_dynamic_truncation", "npp_level_truncation_limit",
 ]
 
 
@@ -110,6 +110,8 @@ def lib():
                                           C.c_void_p]
     L.npp_reach_compile_miss.argtypes = [C.POINTER(C.c_double), C.c_int64] + [C.c_void_p] * 4
     L.npp_reach_rollout_host.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.npp_set_dynamic_truncation.argtypes = [H, C.c_int]
+    L.npp_level_truncation_limit.argtypes = [C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.npp_snapshot.argtypes = [H]
     L.npp_restore.argtypes = [H, C.POINTER(C.c_uint8)]
     L.npp_num_envs.argtypes = [H]

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,9 @@ struct npp_handle_s {
     unsigned long long assign_gen = 0, s_gen = ~0ull;
     int32_t *d_env_level = nullptr;
     int32_t *d_trunc = nullptr;
+    std::vector<int32_t> trunc;            // host mirror of d_trunc
+    bool dyn_trunc = false;                // npp_set_dynamic_truncation: per-level limit from the reachable surface area
+    std::vector<int32_t> level_trunc;      // [n_levels] that limit (empty = not computed for the loaded set)
     uint8_t *d_mask = nullptr;
     unsigned char *d_blob = nullptr;
     uint8_t *d_canvas = nullptr;   // tile-layer coverage canvas of every level (render paths; built on first use)
@@ -331,6 +335,33 @@ int ensure_reach(npp_handle h) {
     return rc;
 }
 
+// calculate_truncation_limit(surface_area, 0) (gym_environment/truncation_calculator.py:19-57; the env passes 0 mines,
+// npp_environment.py:1238-1256): int(clip((sqrt(area) * 20.0 + 0 * 75.0) * 25, 1200, 10000))
+int32_t truncation_limit_for_area(int surface_area) {
+    // the PBRS calculator's fallback when the flood fill finds nothing (reward_calculation/pbrs_potentials.py:885-895)
+    const double area = surface_area > 0 ? (double)surface_area : 1000.0;
+    double v = (std::sqrt(area) * 20.0 + 0.0 * 75.0) * 25.0;
+    v = v < 1200.0 ? 1200.0 : (v > 10000.0 ? 10000.0 : v);
+    return (int32_t)v;
+}
+
+// envs selected by mask (NULL = all) take their level's dynamic limit
+int apply_dynamic_truncation(npp_handle h, const uint8_t *mask) {
+    if (h->level_trunc.size() != h->levels.size()) {
+        h->level_trunc.resize(h->levels.size());
+        for (size_t i = 0; i < h->levels.size(); i++) {
+            ReachBuilt R;
+            build_reach(h->levels[i], R);
+            h->level_trunc[i] = truncation_limit_for_area(R.spawn_area);
+        }
+    }
+    for (int e = 0; e < h->n; e++)
+        if (!mask || mask[e]) h->trunc[e] = h->level_trunc[h->env_level[e]];
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_trunc, h->trunc.data(), sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
+    return NPP_OK;
+}
+
 // `fresh` = the entities are created for the first time since the level was assigned (the state a replay starts from);
 // any later reset is a Simulator.reset(), after which Entity.index no longer starts at 0 (see ZOO_HEAD in npp_internal.hpp)
 int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh, int fast = 0, int automatic = 0) {
@@ -381,8 +412,8 @@ int npp_create(int n_envs, int device_id, unsigned flags, npp_handle *out) {
         return fail(nullptr, NPP_ERR_HIP, "npp_create: hipMalloc failed");
     }
     h->env_level.assign(N, 0);
-    std::vector<int32_t> lim(N, 10000);  // MAX_TIME_IN_FRAMES fallback (gym_environment/constants.py:8)
-    hipMemcpy(h->d_trunc, lim.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice);
+    h->trunc.assign(N, 10000);  // MAX_TIME_IN_FRAMES fallback (gym_environment/constants.py:8)
+    hipMemcpy(h->d_trunc, h->trunc.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice);
     hipMemset(h->d_env_level, 0, sizeof(int32_t) * N);
     *out = h;
     return NPP_OK;
@@ -634,6 +665,9 @@ int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, in
         return fail(h, NPP_ERR_INVALID, "npp_load_levels: entity tables exceed LDS");
     std::fill(h->env_level.begin(), h->env_level.end(), 0);
     HIP_TRY(h, hipMemset(h->d_env_level, 0, sizeof(int32_t) * (size_t)h->n));
+    h->level_trunc.clear();
+    if (h->dyn_trunc)
+        if (int rc = apply_dynamic_truncation(h, nullptr)) return rc;
     return reset_impl(h, nullptr, 1);
 }
 
@@ -665,6 +699,8 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
         HIP_TRY(h, launch_reach_restore(a, nullptr, nullptr, h->d_rkey, h->d_rcache, h->rmiss, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    if (h->dyn_trunc)
+        if (int rc = apply_dynamic_truncation(h, mask.data())) return rc;
     return reset_impl(h, mask.data(), 1);
 }
 
@@ -682,10 +718,28 @@ int npp_reset_ex(npp_handle h, const uint8_t *env_mask, int mode) {
 int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
     if (!h) return NPP_ERR_INVALID;
     ON_DEVICE(h);
-    std::vector<int32_t> lim;
-    if (!limits) { lim.assign(h->n, all); limits = lim.data(); }
+    if (limits) h->trunc.assign(limits, limits + h->n);
+    else h->trunc.assign(h->n, all);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(h->d_trunc, limits, sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_trunc, h->trunc.data(), sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
+    return NPP_OK;
+}
+
+int npp_set_dynamic_truncation(npp_handle h, int enable) {
+    if (!h) return NPP_ERR_INVALID;
+    h->dyn_trunc = enable != 0;
+    if (!h->dyn_trunc || h->levels.empty()) return NPP_OK;
+    ON_DEVICE(h);
+    return apply_dynamic_truncation(h, nullptr);
+}
+
+int npp_level_truncation_limit(const double *map, int64_t n, int32_t *limit, int32_t *surface_area) {
+    if (!map) return NPP_ERR_INVALID;
+    ReachBuilt R;
+    std::string err;
+    if (!build_reach(map, n, R, err)) return NPP_ERR_INVALID;
+    if (limit) *limit = truncation_limit_for_area(R.spawn_area);
+    if (surface_area) *surface_area = R.spawn_area;
     return NPP_OK;
 }
 

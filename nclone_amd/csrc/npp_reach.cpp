@@ -546,6 +546,11 @@ void build_reach(const CompiledLevel &L, ReachBuilt &R) {
         const double sx = (double)((long)L.spawn_x + 24), sy = (double)((long)L.spawn_y + 24);
         const int cnt = n_adj ? flood_fill(fin, R.phys, sx, sy, reach) : 0;
         R.surface_area = cnt;
+        R.spawn_area = cnt;
+        if (cnt == 0 && n_adj) {   // the PBRS calculator's own flood fill starts at int(spawn) (pbrs_potentials.py:876-886); it only
+            std::vector<uint8_t> r2;   // runs when the feature code's call above failed (both share one cache entry per level)
+            R.spawn_area = flood_fill(fin, R.phys, (double)(long)L.spawn_x, (double)(long)L.spawn_y, r2);
+        }
         H.area_scale = cnt > 0 ? std::sqrt((double)cnt) * 12.0 : std::sqrt(1056.0 * 1056.0 + 600.0 * 600.0);
     }
     // ---- level cache: goals exit_switch_0 and exit_door_0

@@ -25,6 +25,7 @@ struct ReachBuilt {
     std::vector<double> astar;                // [n_cand][RNODES] miss branch: physics A* cost to hdr.cand[k] (NaN = not tabulated)
     bool has_sdf = false;
     int surface_area = 0;                     // node count of the area-scale flood fill (0 = it failed)
+    int spawn_area = 0;                       // what the reference's truncation limit sees: the same, or the fill from the true spawn
     std::string note;                         // why hdr.supported == 0
 };
 

@@ -227,6 +227,11 @@ class NppBatch:
             assert len(lim) == self.n
             nat.check(self.h, self.lib.npp_set_truncation_limit(self.h, lim.ctypes.data_as(C.POINTER(C.c_int32)), 0))
 
+    def set_dynamic_truncation(self, enable=True):
+        """The reference env's per-level limit: int(clip(sqrt(reachable surface area) * 500, 1200, 10000)) frames
+        (truncation_calculator.py:19-57), re-applied at every level (re)assignment."""
+        nat.check(self.h, self.lib.npp_set_dynamic_truncation(self.h, 1 if enable else 0))
+
     def set_launch_geometry(self, lanes_per_env=0, waves_per_block=0):
         nat.check(self.h, self.lib.npp_set_launch_geometry(self.h, int(lanes_per_env), int(waves_per_block)))
 
@@ -431,6 +436,15 @@ def reach_level_info(map_data):
     nat.check(None, L.npp_reach_compile(m.ctypes.data_as(C.POINTER(C.c_double)), len(m), info.ctypes.data_as(C.c_void_p),
                                         *([None] * 11)))
     return {"supported": bool(info[0]), "nodes": int(info[1]), "mines": int(info[11]), "surface_area": int(info[13])}
+
+
+def level_truncation_limit(map_data):
+    """Host-only: (dynamic truncation limit in frames, reachable surface area in graph nodes) of one level."""
+    L = nat.lib()
+    m = np.ascontiguousarray(np.asarray(map_data, dtype=np.float64))
+    lim, area = C.c_int32(0), C.c_int32(0)
+    nat.check(None, L.npp_level_truncation_limit(m.ctypes.data_as(C.POINTER(C.c_double)), len(m), C.byref(lim), C.byref(area)))
+    return lim.value, area.value
 
 
 def compile_level_zoo(map_data):

@@ -24,9 +24,9 @@ MAX_TIME_IN_FRAMES = 10000   # gym_environment/constants.py:8-10
 
 def calculate_truncation_limit(surface_area, reachable_mine_count=0):
     """Dynamic truncation limit of the reference (gym_environment/truncation_calculator.py:19-57):
-    clip((sqrt(surface_area) * 20 + mines * 75) * 25, 1200, MAX_TIME_IN_FRAMES).  `surface_area` (reachable graph nodes)
-    comes from the reference's reachability graph, which stays in the reference; pass the result to
-    NppBatch.set_truncation_limit / NppVecEnvironment(truncation_limit=...)."""
+    clip((sqrt(surface_area) * 20 + mines * 75) * 25, 1200, MAX_TIME_IN_FRAMES).  `surface_area` = reachable graph nodes
+    (engine.level_truncation_limit computes both for a level).  The native path applies it per level by itself:
+    NppVecEnvironment(truncation_limit="dynamic"), the default, = npp_set_dynamic_truncation."""
     v = (np.sqrt(surface_area) * 20.0 + reachable_mine_count * 75.0) * 25
     return int(np.clip(v, 1200, MAX_TIME_IN_FRAMES))
 
@@ -43,12 +43,16 @@ class NppVecEnvironment:
     level_ids   which level each env plays (default: env i plays level (i // 64) % n_levels, so every 64-env block
                 shares a level and the kernel stages it in LDS)
     output      "torch" (CUDA tensors, zero copies) or "numpy" (host copies; drop-in for numpy training loops)
+    truncation_limit  "dynamic" (default; the reference env's per-level limit from the reachable surface area,
+                npp_environment.py:1238-1256) or a number of frames for every env (10000 = the reference's fallback)
+    The step's `reward` carries only the sparse terminal constants -- reward parity: NONE (the reference's PBRS reward
+    calculator is out of scope); compute the reward from the observations / info flags.
     """
 
     metadata = {"render_modes": []}
 
     def __init__(self, levels, num_envs, level_ids=None, frame_skip=4, device=0, enable_visual_observations=False,
-                 truncation_limit=10000, output="torch", autoreset=True, enable_spatial_context=False,
+                 truncation_limit="dynamic", output="torch", autoreset=True, enable_spatial_context=False,
                  enable_switch_states=False, fast_reset=True, stream=None, enable_reachability=False):
         assert output in ("torch", "numpy")
         self.num_envs = int(num_envs)
@@ -78,7 +82,13 @@ class NppVecEnvironment:
         if level_ids is None:
             level_ids = (np.arange(self.num_envs) // 64) % len(levels)
         self._b.assign_levels(level_ids)
-        self._b.set_truncation_limit(truncation_limit)
+        if isinstance(truncation_limit, str):
+            if truncation_limit != "dynamic":
+                raise ValueError('truncation_limit: a number of frames or "dynamic"')
+            self._b.set_dynamic_truncation(True)
+        else:
+            self._b.set_truncation_limit(truncation_limit)
+        self._rng = np.random.default_rng()
         with self._b._ctx():
             self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
         self._reset_bits = 11 if autoreset else 0
@@ -118,13 +128,58 @@ class NppVecEnvironment:
     # -- Gymnasium surface ----------------------------------------------------------------------------------------
     def reset(self, seed=None, options=None):
         """Reset every env to its level's spawn state (npp_environment.py:504).  The first reset of a level assignment is
-        Simulator.reset (nsim.py:62); later ones are Simulator.fast_reset (nsim.py:78) unless fast_reset=False."""
-        self._b.reset()
+        Simulator.reset (nsim.py:62); later ones are Simulator.fast_reset (nsim.py:78) unless fast_reset=False.
+
+        seed     seeds `action_space_sample()` only: the reference's seed picks the next map (env_map_loader.py), here the
+                 levels are assigned explicitly, and the simulation itself has no randomness.
+        options  {"checkpoint": c} restores a Go-Explore checkpoint (base_environment.py:1769-1789, _reset_to_checkpoint):
+                 c = "snapshot" puts back the state saved by `snapshot()` (a device-side copy: what the replay below would
+                 reproduce, bit for bit); otherwise c (or c["action_sequence"] / c.action_sequence) is the action sequence to
+                 replay from the spawn -- one sequence for every env, or an [N, K] array -- frame_skip ticks per action like
+                 ActionReplayer.replay_to_checkpoint; c.source_frame_skip / c["source_frame_skip"] overrides the tick count.
+                 Other keys of the reference (skip_map_load, new_level, map_name) concern its map loader and are ignored."""
+        if seed is not None:
+            self._rng = np.random.default_rng(seed)
+        ckpt = (options or {}).get("checkpoint")
+        info = {}
+        if isinstance(ckpt, str):
+            if ckpt != "snapshot":
+                raise ValueError('options["checkpoint"]: "snapshot", an action sequence, or an object with .action_sequence')
+            self._b.restore()
+            info = {"checkpoint_replay": False, "restored_snapshot": True}
+        else:
+            self._b.reset()
+            if ckpt is not None:
+                seq = ckpt.get("action_sequence") if isinstance(ckpt, dict) else getattr(ckpt, "action_sequence", ckpt)
+                fs = ckpt.get("source_frame_skip") if isinstance(ckpt, dict) else getattr(ckpt, "source_frame_skip", None)
+                seq = np.asarray(seq if seq is not None else [], dtype=np.uint8)
+                if seq.ndim == 1:
+                    seq = np.broadcast_to(seq[None, :], (self.num_envs, len(seq)))
+                if seq.ndim != 2 or seq.shape[0] != self.num_envs:
+                    raise ValueError("checkpoint action_sequence: [K] or [num_envs, K]")
+                K = int(seq.shape[1])
+                if K:
+                    fs = self.frame_skip if fs is None else int(fs)
+                    with self._b._ctx():
+                        acts = torch.from_numpy(np.ascontiguousarray(seq.T)).to(self._b.device)
+                    flags, _rew, frames = self._b.step_many(acts, fs)
+                    info = {"checkpoint_replay": True, "replay_frames": frames.to(torch.int64).sum(dim=0),
+                            "replay_terminated": (flags & 3).ne(0).any(dim=0)}
+                else:
+                    info = {"checkpoint_replay": False, "replay_frames": 0}
         self._b.observe()
         self._produce()
         if self.output == "torch":
-            return self._obs(self._b.out.t), {}
-        return self._obs(self._b.to_host(self._obs_names)), {}
+            return self._obs(self._b.out.t), info
+        return self._obs(self._b.to_host(self._obs_names)), info
+
+    def snapshot(self):
+        """Save the state of every env on the device (one slot); reset(options={"checkpoint": "snapshot"}) restores it."""
+        self._b.snapshot()
+
+    def action_space_sample(self):
+        """uint8 [N] uniform actions from the generator reset(seed=...) seeds."""
+        return self._rng.integers(0, 6, size=self.num_envs).astype(np.uint8)
 
     def step_async(self, actions):
         """Enqueue the step (action upload, step kernel, observation kernels) on the handle's stream; returns at once."""
@@ -177,7 +232,7 @@ class NppEnvironment:
     throughput."""
 
     def __init__(self, map_data=None, custom_map_path=None, frame_skip=4, device=0, enable_visual_observations=False,
-                 truncation_limit=10000, fast_reset=True, enable_spatial_context=False, enable_switch_states=False,
+                 truncation_limit="dynamic", fast_reset=True, enable_spatial_context=False, enable_switch_states=False,
                  enable_reachability=False):
         if map_data is None:
             if custom_map_path is None:

@@ -201,3 +201,138 @@ def test_bench_two_ranks_default_line_reports_config4():
     c4 = line["config4"]
     assert "config 4" in c4["config"]["workload"] and c4["value"] > 0
     assert c4["with_obs_gather"]["own_shard_roundtrip_ok"] and c4["with_obs_gather"]["value"] > 0
+
+
+def test_dynamic_truncation_limit_on_the_device():
+    """npp_set_dynamic_truncation: every env truncates at its LEVEL's limit (int(clip(sqrt(surface area) * 500, 1200, 10000)),
+    pinned against the reference function in test_host_cpu.py) and game_state[40] = max(0, (limit - frame) / limit); a reassigned
+    env follows its new level; a manual limit overrides until the next assignment."""
+    from nclone_amd.engine import NppBatch, level_truncation_limit
+    from nclone_amd.levels import curriculum0_levels, door_levels
+
+    cand = curriculum0_levels()[0][:40] + door_levels()[0]
+    lims = [level_truncation_limit(m)[0] for m in cand]
+    pick = [int(np.argmin(lims)), int(np.argsort(lims)[len(lims) // 2]), int(np.argmax(lims))]
+    levels = [cand[i] for i in pick]
+    L = [lims[i] for i in pick]
+    assert L[0] == 1200 and L[0] < L[1] <= L[2]
+    n = 192
+    lvl = np.arange(n) // 64
+    b = NppBatch(n, autoreset=True)
+    b.load_levels(levels)
+    b.assign_levels(lvl)
+    b.set_dynamic_truncation(True)
+    b.reset()
+    noop = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    first_trunc = np.full(n, -1)
+    frames_alive = np.zeros(n, dtype=np.int64)
+    lim_e = np.array(L)[lvl]
+    for s in range(L[1] // 4 + 8):
+        b.step(noop)
+        h = b.to_host(("flags", "frames", "game_state"))
+        fl = h["flags"]
+        frames_alive += h["frames"].astype(np.int64)
+        trunc = (fl & 8) != 0
+        done = (fl & 11) != 0
+        # an env still in its episode: time_remaining of the observation = (limit - frame) / limit
+        alive = ~done
+        exp = np.maximum(0.0, (lim_e - frames_alive) / lim_e).astype(np.float32)
+        assert np.array_equal(h["game_state"][alive, 40], exp[alive]), s
+        assert not (trunc & (frames_alive < lim_e)).any(), s          # never before the level's limit
+        first_trunc[(first_trunc < 0) & trunc] = s
+        frames_alive[done] = 0
+    # standing still nothing else ends the episode on these levels for at least some envs: they truncate exactly at the limit
+    for k in (0, 1):
+        sel = (lvl == k) & (first_trunc >= 0)
+        assert sel.any() and (first_trunc[sel] == (L[k] + 3) // 4 - 1).all(), (k, L[k], np.unique(first_trunc[sel]))
+    # reassignment: the first 64 envs move to the level with the middle limit; a manual limit holds until then
+    b.set_truncation_limit(40)
+    b.assign_levels(np.full(64, 1, dtype=np.int32), env_ids=np.arange(64, dtype=np.int32))
+    b.reset()
+    b.step(noop)
+    gs = b.to_host(("game_state",))["game_state"]
+    assert np.array_equal(gs[:64, 40], np.full(64, np.float32((L[1] - 4) / L[1])))
+    assert np.array_equal(gs[64:128, 40], np.full(64, np.float32((40 - 4) / 40)))
+    b.close()
+
+
+def test_reset_checkpoint_option_and_seed():
+    """NppVecEnvironment.reset(options={"checkpoint": ...}) (base_environment.py:1769-1789): an action sequence is replayed from the
+    spawn (frame_skip ticks per action, as ActionReplayer does), "snapshot" restores the device-side copy -- both give the state
+    the original episode had, bit for bit; seed= makes action_space_sample() reproducible."""
+    from nclone_amd.levels import door_levels, mine_levels
+    from nclone_amd.vec_env import NppVecEnvironment
+
+    levels = mine_levels()[0][:3] + door_levels()[0][:3]
+    n = 6 * 64
+    v = NppVecEnvironment(levels, n, autoreset=False, truncation_limit=10000)
+    v.reset(seed=7)
+    acts = np.stack([v.action_space_sample() for _ in range(25)])
+    v.reset(seed=7)
+    assert np.array_equal(acts, np.stack([v.action_space_sample() for _ in range(25)]))
+    for t in range(25):
+        v.step(acts[t])
+    f0, i0 = v.batch.dump_state()
+    obs0 = {k: (x.clone() if isinstance(x, torch.Tensor) else x) for k, x in v.batch.out.t.items()}
+    v.snapshot()
+    for t in range(10):
+        v.step(acts[t])
+    f1, _ = v.batch.dump_state()
+    assert not np.array_equal(f0, f1)
+    obs, info = v.reset(options={"checkpoint": "snapshot"})
+    f2, i2 = v.batch.dump_state()
+    assert np.array_equal(f0, f2) and np.array_equal(i0[:, :26], i2[:, :26]) and info["restored_snapshot"]
+    assert torch.equal(obs["game_state"], obs0["game_state"])
+    # replay: per-env sequences [N, K] and one shared sequence
+    obs, info = v.reset(options={"checkpoint": {"action_sequence": acts.T}})
+    f3, i3 = v.batch.dump_state()
+    assert info["checkpoint_replay"] and np.array_equal(f0, f3) and np.array_equal(i0[:, :26], i3[:, :26])
+    assert torch.equal(obs["game_state"], obs0["game_state"])
+
+    class Ckpt:                      # the attribute names of the reference's StateCheckpoint (state_checkpoint.py)
+        action_sequence = [2, 2, 5, 5, 2, 0, 1, 4]
+        source_frame_skip = 4
+
+    obs, info = v.reset(options={"checkpoint": Ckpt()})
+    f4, _ = v.batch.dump_state()
+    v.reset()
+    for a in Ckpt.action_sequence:
+        v.step(np.full(n, a, dtype=np.uint8))
+    f5, _ = v.batch.dump_state()
+    assert np.array_equal(f4, f5)
+    with pytest.raises(ValueError):
+        v.reset(options={"checkpoint": {"action_sequence": np.zeros((3, 4), np.uint8)}})
+    v.close()
+
+
+def test_switch_states_match_the_reference_methods():
+    """switch_states against the reference's OWN code: tests/golden/obs.npz holds what NppEnvironment._build_switch_states_array /
+    _extract_locked_door_positions (npp_environment.py:1782-1847; run by tests/golden/make_golden_obs.py) return on the live
+    locked-door entities along 400-step rollouts of the 21 door levels -- collected flags flipping as switches are touched and
+    coming back after resets, the 'door' position falling back to the switch's, six doors cut to five.  Bit for bit, every step."""
+    from nclone_amd.engine import NppBatch
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "obs.npz"))
+    names = bytes(z["names"]).decode().split("\n")
+    n = len(names)
+    assert n == 21
+    b = NppBatch(n, autoreset=True, outputs=("positions", "switch_states"), fast_reset=False)   # the fixture resets with Simulator.reset
+    b.load_levels([z["m%d" % k] for k in range(n)])
+    b.assign_levels(np.arange(n))
+    b.set_truncation_limit(100000)
+    A = np.stack([z["a%d" % k] for k in range(n)])
+    P = np.stack([z["p%d" % k] for k in range(n)])
+    S = np.stack([z["s%d" % k] for k in range(n)])
+    assert (S[:, :, 4::5] == 1).any() and (S[:, :, 4::5] == 0).any() and (S[19, 0, :25:5] > 0).all()
+    b.observe()
+    b.switch_states()
+    h = b.to_host(("positions", "switch_states"))
+    assert np.array_equal(h["switch_states"], S[:, 0])
+    for t in range(A.shape[1]):
+        b.step(torch.from_numpy(np.ascontiguousarray(A[:, t])).cuda())
+        b.switch_states()
+        h = b.to_host(("positions", "switch_states"))
+        assert np.array_equal(h["positions"][:, :2], P[:, t + 1]), t
+        bad = np.flatnonzero((h["switch_states"] != S[:, t + 1]).any(axis=1))
+        assert len(bad) == 0, (t, [names[i] for i in bad])
+    b.close()

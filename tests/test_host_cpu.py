@@ -213,3 +213,28 @@ def test_aabb_threshold_table_is_exact():
         for _ in range(64):
             assert not (np.float64(x - ten) <= b), i
             x = np.nextafter(x, np.inf)
+
+
+def test_dynamic_truncation_limit_matches_reference():
+    """npp_level_truncation_limit (the per-level limit npp_set_dynamic_truncation applies) and the Python helper against the
+    reference's calculate_truncation_limit (tests/golden/trunc.npz: the function itself called on areas 0..4000 and on the
+    surface areas of the 126 reachability fixture levels), and the surface area against the reference's `sa<k>`."""
+    from nclone_amd.engine import level_truncation_limit
+    from nclone_amd.vec_env import calculate_truncation_limit
+
+    t = np.load(os.path.join(ROOT, "tests", "golden", "trunc.npz"))
+    ref = {int(a): int(v) for a, v in zip(t["area"], t["limit"])}
+    for a, v, vm in zip(t["area"], t["limit"], t["limit_mines"]):
+        assert calculate_truncation_limit(int(a)) == int(v)
+        assert [calculate_truncation_limit(int(a), m) for m in (1, 2, 5, 20)] == [int(x) for x in vm]
+    assert 1200 in ref.values() and 10000 in ref.values() and len(set(ref.values())) > 300
+    seen = set()
+    for fx in ("reach.npz", "reach2.npz"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", fx))
+        for k, name in enumerate(bytes(z["names"]).decode().split("\n")):
+            lim, area = level_truncation_limit(z["m%d" % k])
+            sa = int(z["sa%d" % k][0])
+            assert area == sa and sa > 0, name
+            assert lim == ref[sa], (name, sa)
+            seen.add(lim)
+    assert len(seen) > 20 and min(seen) == 1200
