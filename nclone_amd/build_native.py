@@ -10,8 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnpp_amd.so")
-SOURCES = ["npp_kernels.hip", "npp_render.hip", "npp_reach_kernel.hip", "npp_capi.cpp", "npp_level.cpp", "npp_reach.cpp"]
+SOURCES = ["npp_kernels.hip", "npp_render.hip", "npp_reach_kernel.hip", "npp_capi.cpp", "npp_level.cpp", "npp_reach.cpp", "npp_host.cpp"]
 HEADERS = ["npp_internal.hpp", "npp_level.hpp", "npp_zoo.hpp", "npp_reach.hpp", "npp_reach_build.hpp", "npp_reach_features.hpp",
+           "npp_host.hpp", "npp_zoo_layout.hpp",
            "npp_reach_tables.inc", os.path.join("..", "..", "include", "npp_amd.h")]
 
 
@@ -41,7 +42,7 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
     jobs = [("npp_kernels.hip", ["-DNPP_TU=%d" % k], "npp_kernels_tu%d.o" % k) for k in range(4)]
     jobs += [("npp_render.hip", [], "npp_render.o"), ("npp_capi.cpp", [], "npp_capi.o"), ("npp_level.cpp", [], "npp_level.o"),
-             ("npp_reach_kernel.hip", [], "npp_reach_kernel.o"), ("npp_reach.cpp", [], "npp_reach.o")]
+             ("npp_reach_kernel.hip", [], "npp_reach_kernel.o"), ("npp_reach.cpp", [], "npp_reach.o"), ("npp_host.cpp", [], "npp_host.o")]
     procs = []
     for src, extra, obj in jobs:
         cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)]
@@ -53,6 +54,27 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
             raise subprocess.CalledProcessError(p.returncode, cmd)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [os.path.join(objdir, j[2]) for j in jobs])
     return out
+
+
+HOST_SOURCES = ["npp_level.cpp", "npp_reach.cpp", "npp_host.cpp"]   # no HIP header anywhere below them
+SANITIZED = os.path.join(HERE, "libnpp_host_asan.so")
+
+
+def build_sanitized(force=False):
+    """The GPU-free part of the library (level compiler, reachability table builder, host-only C entries) compiled with
+    g++ -fsanitize=address,undefined into a TEST-ONLY library (the build needs its own sanitizer run; GPU
+    AddressSanitizer is not available on the pool).  tests/test_host_sanitized.py loads it in a child process under
+    LD_PRELOAD=libasan and runs the host checks plus a malformed-map fuzz."""
+    srcs = [os.path.join(CSRC, f) for f in HOST_SOURCES]
+    if not force and os.path.isfile(SANITIZED):
+        t = os.path.getmtime(SANITIZED)
+        if all(os.path.getmtime(os.path.join(CSRC, f)) <= t for f in HOST_SOURCES + HEADERS):
+            return SANITIZED
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include"),
+           "-o", SANITIZED] + srcs
+    subprocess.check_call(cmd)
+    return SANITIZED
 
 
 if __name__ == "__main__":

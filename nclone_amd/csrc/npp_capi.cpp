@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/npp_amd.h"
+#include "npp_host.hpp"
 #include "npp_internal.hpp"
 #include "npp_level.hpp"
 #include "npp_reach_build.hpp"
@@ -87,14 +88,13 @@ struct npp_handle_s {
     std::string err;
 };
 
-static thread_local std::string g_create_err;
 
 namespace {
 
 constexpr uint32_t LDS_BUDGET = 64 * 1024;  // per workgroup (160 KiB per CU: at least two workgroups per CU)
 
 int fail(npp_handle h, int code, const std::string &msg) {
-    if (h) h->err = msg; else g_create_err = msg;
+    if (h) h->err = msg; else host_error() = msg;
     return code;
 }
 
@@ -123,16 +123,6 @@ struct DeviceGuard {
 #define ON_DEVICE(h)                                                                                          \
     DeviceGuard _dg((h)->device);                                                                             \
     if (_dg.err != hipSuccess) return fail(h, NPP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dg.err))
-
-// The per-env zoo block must hold the doors and movers of EVERY level of the set: the reset kernel writes n_zdoor door
-// words and n_mov mover records for whatever level an env plays, zoo level or not (a locked door has an edge counter too).
-void zoo_block_plan(const std::vector<CompiledLevel> &lv, int &doors, int &movers) {
-    doors = 0; movers = 0;
-    for (const CompiledLevel &L : lv) {
-        doors = std::max(doors, (int)(L.door_tab.size() / 2));
-        movers = std::max(movers, (int)L.mov_meta.size());
-    }
-}
 
 // Launch geometry (DESIGN.md "lanes per environment"): G lanes cooperate on one env.  The chip has 256 CUs x 4 SIMDs;
 // the path is a latency-bound fp64 dependency chain, so the grid is sized to put about two wavefronts on every SIMD
@@ -335,16 +325,6 @@ int ensure_reach(npp_handle h) {
     return rc;
 }
 
-// calculate_truncation_limit(surface_area, 0) (gym_environment/truncation_calculator.py:19-57; the env passes 0 mines,
-// npp_environment.py:1238-1256): int(clip((sqrt(area) * 20.0 + 0 * 75.0) * 25, 1200, 10000))
-int32_t truncation_limit_for_area(int surface_area) {
-    // the PBRS calculator's fallback when the flood fill finds nothing (reward_calculation/pbrs_potentials.py:885-895)
-    const double area = surface_area > 0 ? (double)surface_area : 1000.0;
-    double v = (std::sqrt(area) * 20.0 + 0.0 * 75.0) * 25.0;
-    v = v < 1200.0 ? 1200.0 : (v > 10000.0 ? 10000.0 : v);
-    return (int32_t)v;
-}
-
 // envs selected by mask (NULL = all) take their level's dynamic limit
 int apply_dynamic_truncation(npp_handle h, const uint8_t *mask) {
     if (h->level_trunc.size() != h->levels.size()) {
@@ -385,7 +365,7 @@ int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh, int fast = 0, i
 
 extern "C" {
 
-const char *npp_last_error(npp_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+const char *npp_last_error(npp_handle h) { return h ? h->err.c_str() : host_error().c_str(); }
 
 int npp_create(int n_envs, int device_id, unsigned flags, npp_handle *out) {
     if (!out || n_envs <= 0) return fail(nullptr, NPP_ERR_INVALID, "npp_create: n_envs must be > 0 and out non-NULL");
@@ -733,15 +713,6 @@ int npp_set_dynamic_truncation(npp_handle h, int enable) {
     return apply_dynamic_truncation(h, nullptr);
 }
 
-int npp_level_truncation_limit(const double *map, int64_t n, int32_t *limit, int32_t *surface_area) {
-    if (!map) return NPP_ERR_INVALID;
-    ReachBuilt R;
-    std::string err;
-    if (!build_reach(map, n, R, err)) return NPP_ERR_INVALID;
-    if (limit) *limit = truncation_limit_for_area(R.spawn_area);
-    if (surface_area) *surface_area = R.spawn_area;
-    return NPP_OK;
-}
 
 #ifndef NPP_STEP_FOLD
 #define NPP_STEP_FOLD 0
@@ -1112,88 +1083,6 @@ int npp_dump_level_segments(npp_handle h, int level, int16_t *out, int max_rows,
     int r = dump_segments(h->levels[level], out, max_rows);
     if (r < 0) return fail(h, NPP_ERR_INVALID, "npp_dump_level_segments: buffer too small");
     *n_out = r;
-    return NPP_OK;
-}
-
-int npp_compile_level_segments(const double *map, int64_t n, int16_t *out, int max_rows, int *n_out, uint32_t *unsupported_mask) {
-    if (!map || !out || !n_out) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_segments: bad arguments");
-    CompiledLevel L;
-    std::string err;
-    if (!compile_level(map, n, L, err)) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_segments: " + err);
-    int r = dump_segments(L, out, max_rows);
-    if (r < 0) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_segments: buffer too small");
-    *n_out = r;
-    if (unsupported_mask) *unsupported_mask = L.unsupported_mask;
-    return NPP_OK;
-}
-
-int npp_compile_level_zoo(const double *map, int64_t n, int32_t *edges_out, double *movers_out, int max_movers, int *n_movers) {
-    if (!map || !edges_out || !n_movers) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_zoo: bad arguments");
-    CompiledLevel L;
-    std::string err;
-    if (!compile_level(map, n, L, err)) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_zoo: " + err);
-    const int NK = EDGE_W * EDGE_H;
-    for (int k = 0; k < NK; k++) {
-        edges_out[k] = (int32_t)((L.edges[k >> 5] >> (k & 31)) & 1u);
-        edges_out[NK + k] = (int32_t)((L.edges[EDGE_WORDS + (k >> 5)] >> (k & 31)) & 1u);
-    }
-    for (size_t d = 0; d + 1 < L.door_tab.size(); d += 2) {
-        uint32_t keys[2] = {L.door_tab[d] & 0xffffu, L.door_tab[d] >> 16};
-        for (uint32_t k : keys) edges_out[((k & 0x8000u) ? NK : 0) + (int)(k & 0x7fffu)] += (int32_t)(L.door_tab[d + 1] & 0xffu);
-    }
-    int nm = (int)L.mov_meta.size();
-    if (movers_out) {
-        if (nm > max_movers) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_zoo: buffer too small");
-        static const double type_of[7] = {0, 14, 17, 20, 25, 26, 28};
-        for (int m = 0; m < nm; m++) {
-            movers_out[4 * m] = type_of[L.mov_meta[m] & 7u];
-            movers_out[4 * m + 1] = L.mov_x0[m];
-            movers_out[4 * m + 2] = L.mov_y0[m];
-            movers_out[4 * m + 3] = (double)(L.mov_meta[m] >> 8);
-        }
-    }
-    *n_movers = nm;
-    return NPP_OK;
-}
-
-int npp_plan_zoo_block(const double *blob, const int64_t *offsets, int n_levels, int *doors, int *movers, int *words) {
-    if (!blob || !offsets || n_levels <= 0) return fail(nullptr, NPP_ERR_INVALID, "npp_plan_zoo_block: bad arguments");
-    std::vector<CompiledLevel> lv(n_levels);
-    for (int i = 0; i < n_levels; i++) {
-        std::string err;
-        if (offsets[i + 1] < offsets[i] || !compile_level(blob + offsets[i], offsets[i + 1] - offsets[i], lv[i], err))
-            return fail(nullptr, NPP_ERR_INVALID, "npp_plan_zoo_block: level " + std::to_string(i) + ": " + err);
-    }
-    int d = 0, m = 0;
-    zoo_block_plan(lv, d, m);
-    if (doors) *doors = d;
-    if (movers) *movers = m;
-    if (words) *words = zoo_words_for(d, m);
-    return NPP_OK;
-}
-
-int npp_compile_level_entities(const double *map, int64_t n, double *out, int max_rows, int *n_out) {
-    if (!map || !out || !n_out) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_entities: bad arguments");
-    CompiledLevel L;
-    std::string err;
-    if (!compile_level(map, n, L, err)) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_entities: " + err);
-    int ne = (int)L.ent_map_order.size();
-    if (ne > max_rows) return fail(nullptr, NPP_ERR_INVALID, "npp_compile_level_entities: buffer too small");
-    // cell of a slot from the CSR
-    std::vector<int> cell_of_slot(ne, 0);
-    for (int c = 0; c < N_CELLS; c++)
-        for (int s = L.ent_start[c]; s < L.ent_start[c + 1]; s++) cell_of_slot[s] = c;
-    for (int i = 0; i < ne; i++) {
-        int s = L.ent_map_order[i];
-        double *o = out + (size_t)i * 6;
-        o[0] = L.ent_meta[s] & 15u;
-        o[1] = L.ent_x[s];
-        o[2] = L.ent_y[s];
-        o[3] = cell_of_slot[s] / GRID_H;
-        o[4] = cell_of_slot[s] % GRID_H;
-        o[5] = (L.ent_meta[s] >> 4) & 3u;
-    }
-    *n_out = ne;
     return NPP_OK;
 }
 

@@ -117,6 +117,13 @@ bool compile_level(const double *map, int64_t n, CompiledLevel &L, std::string &
         err = "map_data shorter than 1233 values";
         return false;
     }
+    // map_data holds bytes (and, for generated maps, small fractional coordinates): anything non-finite or beyond 16 bits is a
+    // corrupted blob -- refused here so that no later stage has to convert an out-of-range double to an integer
+    for (int64_t i = 0; i < n; i++)
+        if (!(std::fabs(map[i]) <= 65535.0)) {
+            err = "map_data[" + std::to_string(i) + "] is not a finite value within +-65535";
+            return false;
+        }
     L = CompiledLevel();
     // ---- tiles: map_data[184:1150] is the 42x23 interior, index x + 42*y; border cells are solid (map_loader.py:22-37)
     L.tiles.assign(N_CELLS, 1);
