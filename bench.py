@@ -360,7 +360,37 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
         gdt, _, _ = timed(P + W, gather)
         parts = b.out.split_packed(gathered, world)
         ok = bool(torch.equal(parts["game_state"][rank].to(b.game_state.device), b.game_state))
+        # the same with the gather taken off the critical path (nclone_amd.distributed.OverlappedObsGather): the collective of step t
+        # runs on a side stream while step t + 1 executes
+        from nclone_amd.distributed import OverlappedObsGather
+
+        og = OverlappedObsGather(packed, world)
+        same = True
+        for k in range(P, P + 3):   # the bytes are those of the serial gather
+            b.step(acts[k], FRAME_SKIP, want_terminal=False)
+            gather()
+            torch.cuda.synchronize()
+            want = gathered.clone().cpu()
+            og.submit()
+            b.step(acts[k + 1], FRAME_SKIP, want_terminal=False)   # overwrites the block before the gather is collected
+            got = og.wait()
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(got.cpu(), want))
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(K):
+            b.step(acts[P + W + k], FRAME_SKIP, want_terminal=False)
+            og.submit()
+            if k:
+                og.wait()
+        og.wait()
+        barrier()
+        odt = max_over_ranks(time.perf_counter() - t0)
         gather_rep = {"value": world * n * K / gdt, "unit": "env-steps/s", "ms_per_step": gdt * 1e3 / K,
+                      "overlapped": {"value": world * n * K / odt, "unit": "env-steps/s", "ms_per_step": odt * 1e3 / K,
+                                     "bytes_equal_serial": same,
+                                     "how": "snapshot of the packed block + all_gather on a side stream while the next step runs "
+                                            "(double-buffered); with gloo the host collective blocks inside wait()"},
                       "bytes_per_rank_per_step": int(packed.numel()), "collective": "all_gather_into_tensor (1 per step)",
                       "own_shard_roundtrip_ok": ok,
                       "fields": "game_state f32[41], entity_positions f32[6], reward f32, frames i16, action_mask i8[6], flags u8"}

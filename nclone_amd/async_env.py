@@ -1,15 +1,19 @@
 """Asynchronous vector environment: S independent sub-batches on S HIP streams.
 
-Why it exists: a synchronous step of N envs lasts as long as the serial fp64 chain of its slowest
-env (an env wedged in a crease runs 4 x 114 depenetration iterations, ~200 us, while the average wavefront needs ~16 us).
-The reference's own trainers are already asynchronous per env (`SubprocVecEnv`, one process per env:
-nclone/gym_environment/environment_factory.py:112-153).  Here the N envs are split into S sub-batches, each with its own
-native handle and HIP stream: `step_async` enqueues the sub-batches without waiting, the GPU overlaps the tail of one
-sub-batch with the bulk of the others, and `step_wait(k)` hands back sub-batch k as soon as ITS stream has drained -- a
-learner can act on sub-batch k while the others are still stepping.
+What it is for: a learner that consumes sub-batches as they arrive, like the reference's own trainers, which are asynchronous
+per env (`SubprocVecEnv`, one process per env: nclone/gym_environment/environment_factory.py:112-153).  The N envs are split
+into S sub-batches, each with its own native handle and HIP stream: `step_async` enqueues the sub-batches without waiting and
+`step_wait(k)` hands back sub-batch k as soon as ITS stream has drained -- a learner can act on sub-batch k while the others are
+still stepping.
+
+What it is NOT (any more): a way to more env-steps/s.  Round 1 measured +15 % over the synchronous step (the tail of one
+sub-batch overlapped the bulk of the others); since the heavy-first launch order and the build-variant autotuner of round 2 the
+synchronous step is the faster one (BENCH_r02: 90.1 M env-steps/s against 60.4 M for 4 x 2048 envs) -- each sub-batch fills a
+quarter of the chip, orders and tunes itself on a quarter of the statistics, and four launches cost four times the host work
+(DESIGN.md section 6).  Use NppVecEnvironment for throughput.
 
 Results are bit-identical to the synchronous NppVecEnvironment on the same envs, levels and actions (envs are independent;
-tests/test_gpu_async.py).
+tests/test_gpu_round2.py::test_async_vec_env_matches_sync).
 """
 import numpy as np
 import torch

@@ -65,7 +65,7 @@ struct npp_handle_s {
     int tune_state = 0;              // 0 = warm-up, 1 .. TUNE_ROUNDS * 3 = measuring windows, > that = waiting for events / decided
     int tune_count = 0;              // launches inside the current state
     bool tuned = false;
-    hipEvent_t tune_ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // window boundaries
+    std::vector<hipEvent_t> tune_ev;   // one (start, end) pair per measured launch: 2 * TUNE_WINDOW * windows
     long tune_since = 0;             // launches since the last decision
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
@@ -127,7 +127,8 @@ struct DeviceGuard {
 // Launch geometry (DESIGN.md "lanes per environment"): G lanes cooperate on one env.  The chip has 256 CUs x 4 SIMDs;
 // the path is a latency-bound fp64 dependency chain, so the grid is sized to put about two wavefronts on every SIMD
 // (one hides the other's latency) and the spare lanes of each wavefront are spent on segment-level parallelism.
-void plan_geometry(npp_handle h) {
+void plan_geometry(npp_handle h, bool keep_tuning = false) {
+    const int zoo_before = h->zoo_active;
     int g = h->lanes_per_env;
     if (const char *ev = std::getenv("NPP_LANES_PER_ENV")) g = std::atoi(ev);
     if (g <= 0) {
@@ -162,11 +163,15 @@ void plan_geometry(npp_handle h) {
         h->lds_hot_cap = cap;
         break;
     }
+    // a new plan (level set, assignment, geometry, zoo kernels on / off) restarts npp_step's variant autotuner; a plan that comes
+    // out the same (npp_restore of a snapshot with the same overrides) keeps the decision
+    const bool same_plan = keep_tuning && g == h->geo_g && wpb == h->geo_wpb && zoo_before == h->zoo_active;
     h->geo_g = g;
     h->geo_wpb = wpb;
-    // a new plan (level set, assignment, overrides, geometry) restarts npp_step's variant autotuner
-    h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
-    h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
+    if (!same_plan) {
+        h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
+        h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
+    }
     // can every workgroup stage ONE level?  (the host owns the env -> level assignment)
     int epb = (64 / g) * wpb;
     int ok = !h->hdrs.empty();
@@ -417,6 +422,10 @@ int npp_destroy(npp_handle h) {
 
 int npp_set_stream(npp_handle h, void *hip_stream) {
     if (!h) return NPP_ERR_INVALID;
+    if (h->stream != (hipStream_t)hip_stream) {   // the autotuner's window events live on the old stream: start its cycle over
+        h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
+        h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
+    }
     h->stream = (hipStream_t)hip_stream;
     return NPP_OK;
 }
@@ -488,7 +497,7 @@ int npp_restore(npp_handle h, const uint8_t *env_mask) {
             if (!env_mask || env_mask[e]) h->ovr[e] = h->s_ovr[e];
         h->n_ovr = 0;
         for (int e = 0; e < h->n; e++) h->n_ovr += h->ovr[e] != 0;
-        plan_geometry(h);
+        plan_geometry(h, true);   // restoring a checkpoint every few hundred steps must not keep the autotuner in its warm-up
     }
     return NPP_OK;
 }
@@ -727,8 +736,11 @@ void tune_reset(npp_handle h) {
     h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
     h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
 }
-// called by npp_step before every launch; returns the variant to launch and records the window boundaries on the stream
-int tune_next(npp_handle h) {
+// called by npp_step before every launch; returns the variant to launch.  *pair >= 0: a measured launch -- npp_step records
+// tune_ev[2 * pair] right before and tune_ev[2 * pair + 1] right after the step kernel, so that only the kernel itself is timed
+// (observation kernels and the caller's own work on the stream, whose cost varies with the state, stay outside: ADVICE r2)
+int tune_next(npp_handle h, int *pair) {
+    *pair = -1;
     if (h->variant_pin >= 0) return h->variant_pin;
     if (h->geo_g != 16 || h->zoo_active) return 0;   // only the plain G = 16 kernels have variants
     if (h->tuned) {
@@ -739,27 +751,36 @@ int tune_next(npp_handle h) {
     const int n_win = 3 * TUNE_ROUNDS;
     if (h->tune_state == 0) {   // warm-up on variant 0
         if (++h->tune_count <= TUNE_WARM) return h->variant;
-        for (auto &e : h->tune_ev)
-            if (!e && hipEventCreate(&e) != hipSuccess) { h->tuned = true; h->variant = 0; return 0; }   // no events: stay on 0
-        hipEventRecord(h->tune_ev[0], h->stream);
+        if (h->tune_ev.empty()) {
+            h->tune_ev.assign((size_t)2 * TUNE_WINDOW * n_win, nullptr);
+            for (auto &e : h->tune_ev)
+                if (hipEventCreate(&e) != hipSuccess) {   // no events: stay on variant 0
+                    for (auto &d : h->tune_ev)
+                        if (d) hipEventDestroy(d);
+                    h->tune_ev.clear();
+                    h->tuned = true; h->variant = 0;
+                    return 0;
+                }
+        }
         h->tune_state = 1; h->tune_count = 0;
     }
     if (h->tune_state <= n_win) {   // window w measures variant (w - 1) % 3
-        if (h->tune_count == TUNE_WINDOW) {
-            hipEventRecord(h->tune_ev[h->tune_state], h->stream);
-            h->tune_state++; h->tune_count = 0;
-        }
-        if (h->tune_state <= n_win) { h->tune_count++; return (h->tune_state - 1) % 3; }
+        const int w = h->tune_state;
+        *pair = (w - 1) * TUNE_WINDOW + h->tune_count;
+        if (++h->tune_count == TUNE_WINDOW) { h->tune_state++; h->tune_count = 0; }
+        return (w - 1) % 3;
     }
-    // all windows recorded: decide as soon as the last boundary has been reached by the GPU (no waiting)
-    if (hipEventQuery(h->tune_ev[n_win]) == hipSuccess) {
+    // all windows recorded: decide as soon as the last launch has been reached by the GPU (no waiting)
+    if (hipEventQuery(h->tune_ev.back()) == hipSuccess) {
         float t[3] = {0.f, 0.f, 0.f};
         bool ok = true;
-        for (int w = 1; w <= n_win; w++) {
-            float ms = 0.f;
-            ok = ok && hipEventElapsedTime(&ms, h->tune_ev[w - 1], h->tune_ev[w]) == hipSuccess;
-            t[(w - 1) % 3] += ms;
-        }
+        for (int w = 0; w < n_win && ok; w++)
+            for (int k = 0; k < TUNE_WINDOW && ok; k++) {
+                float ms = 0.f;
+                const size_t p = (size_t)w * TUNE_WINDOW + k;
+                ok = hipEventElapsedTime(&ms, h->tune_ev[2 * p], h->tune_ev[2 * p + 1]) == hipSuccess;
+                t[w % 3] += ms;
+            }
         int best = 0;
         if (ok) for (int v = 1; v < 3; v++) if (t[v] < t[best]) best = v;
         h->variant = best; h->tuned = true; h->tune_since = 0;
@@ -812,8 +833,12 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
         a.wg_order = h->d_wg_order;
         a.wg_cost = h->d_wg_cost;
     }
-    a.variant = tune_next(h);
-    HIP_TRY(h, launch_step(a, h->stream));
+    int pair = -1;
+    a.variant = tune_next(h, &pair);
+    if (pair >= 0) hipEventRecord(h->tune_ev[2 * (size_t)pair], h->stream);
+    const hipError_t le = launch_step(a, h->stream);
+    if (pair >= 0) hipEventRecord(h->tune_ev[2 * (size_t)pair + 1], h->stream);
+    HIP_TRY(h, le);
     return NPP_OK;
 }
 

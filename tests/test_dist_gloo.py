@@ -131,6 +131,57 @@ def test_packed_observation_block_gather_world_size_2():
         assert np.array_equal(parts["flags"][rank], torch.randint(0, 64, (n,), generator=g).to(torch.uint8).numpy())
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nclone_amd.distributed import OverlappedObsGather
+
+    n = 5000
+    g = torch.Generator().manual_seed(100 + rank)
+    packed = torch.zeros(n, dtype=torch.uint8)
+    og = OverlappedObsGather(packed)
+    serial = torch.empty(world * n, dtype=torch.uint8)
+    ok = True
+    prev = None
+    for step in range(7):
+        packed.copy_(torch.randint(0, 256, (n,), generator=g).to(torch.uint8))       # "step t" writes the block
+        dist.all_gather_into_tensor(serial, packed)                                    # the serial gather of the same bytes
+        og.submit()
+        want = serial.clone()
+        packed.copy_(torch.randint(0, 256, (n,), generator=g).to(torch.uint8))       # "step t + 1" overwrites it before wait()
+        got = og.wait()
+        ok = ok and bool(torch.equal(got, want))
+        if prev is not None:
+            ok = ok and not torch.equal(got, prev)
+        prev = got.clone()
+    # depth 2: two submissions outstanding, collected in order
+    packed.fill_(7 + rank); og.submit(); a = torch.full((n,), 7, dtype=torch.uint8)
+    packed.fill_(9 + rank); og.submit()
+    first, second = og.wait().clone(), og.wait().clone()
+    ok = ok and bool((first[:n] == 7).all() and (first[n:] == 8).all() and (second[:n] == 9).all() and (second[n:] == 10).all())
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_returns_the_serial_bytes():
+    """OverlappedObsGather (the double-buffered config-4 gather) on world_size 2 / gloo / CPU tensors: every
+    step's gathered bytes equal a serial all_gather of the same block even though the block is overwritten before wait()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
 def test_bench_bare_invocation_starts_ranks_and_propagates_failure():
     """`python bench.py --gpus 2` without a launcher starts 2 rank processes itself; here (no GPU) the ranks fail, which must
     surface as a non-zero exit code and no JSON line -- not as a silent 1-rank run."""
@@ -165,4 +216,5 @@ def test_bench_two_ranks_on_one_gpu():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0
     assert line["with_obs_gather"]["own_shard_roundtrip_ok"] and line["with_obs_gather"]["value"] > 0
+    assert line["with_obs_gather"]["overlapped"]["bytes_equal_serial"] and line["with_obs_gather"]["overlapped"]["value"] > 0
     assert line["config"]["preroll_steps"] == 10 and line["launch_us"]["p95"] >= line["launch_us"]["p50"]
