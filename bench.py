@@ -148,6 +148,8 @@ def parse_args(argv=None):
                          "BASELINE configs in their own blocks, see the module docstring")
     ap.add_argument("--other-steps", type=int, default=200,
                     help="timed steps of each block of `other_configs` / `config4` (0 = leave them out)")
+    ap.add_argument("--step-variant", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="pin a build variant of the step kernel (A/B runs); -1 = the autotuner decides (default)")
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
                     help="seconds after which `bench.py --gpus N` gives up on its rank processes")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks itself")
@@ -267,6 +269,8 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
     STAGES = (("switch_states", lambda: b.switch_states()), ("player_frame", lambda: b.render_player_frame()),
               ("global_view", lambda: b.render_global_view()), ("reachability", lambda: b.reachability())) if full_obs else ()
     b.load_levels(levels)
+    if args.step_variant >= 0:
+        b.set_step_variant(args.step_variant)
     # 64 consecutive envs (one wavefront / workgroup) per level, levels repeated round-robin; with more ranks than one the
     # global env index decides, so that 8 x 8192 envs cover all 512 levels of the mixed set twice
     env_level = ((np.arange(n) + rank * n) // 64) % len(levels)

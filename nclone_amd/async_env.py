@@ -82,7 +82,7 @@ class NppAsyncVecEnvironment:
     step_async_partial(k, actions) re-enqueue just sub-batch k
     """
 
-    def __init__(self, levels, num_envs, n_streams=4, level_ids=None, frame_skip=4, device=0, truncation_limit=10000,
+    def __init__(self, levels, num_envs, n_streams=4, level_ids=None, frame_skip=4, device=0, truncation_limit="dynamic",
                  output="numpy", autoreset=True, fast_reset=True):
         assert output in ("torch", "numpy")
         self.num_envs, self.frame_skip, self.output = int(num_envs), int(frame_skip), output
@@ -92,7 +92,13 @@ class NppAsyncVecEnvironment:
         if level_ids is None:
             level_ids = (np.arange(self.num_envs) // 64) % len(levels)
         self.ab.assign_levels(level_ids)
-        self.ab.set_truncation_limit(truncation_limit)
+        if isinstance(truncation_limit, str):   # "dynamic": the reference env's per-level limit, as in NppVecEnvironment
+            if truncation_limit != "dynamic":
+                raise ValueError('truncation_limit: a number of frames or "dynamic"')
+            for b in self.ab.batches:
+                b.set_dynamic_truncation(True)
+        else:
+            self.ab.set_truncation_limit(truncation_limit)
         self._reset_bits = 11 if autoreset else 0   # won | dead | truncated: the row holds the spawn observation
         self._acts = []
         for b in self.ab.batches:

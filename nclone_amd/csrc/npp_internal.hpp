@@ -126,10 +126,20 @@ constexpr int EDGE_WORDS_D = 142;   // == npp::EDGE_WORDS (npp_level.hpp)
 
 // Launch geometry: G lanes cooperate on one environment (G in {1,2,4,8,16,32,64}); a wavefront holds 64/G envs; a
 // workgroup holds WPB wavefronts that share one LDS copy of a level when all their envs play the same level.
-// dynamic LDS layout: [hot_cap][ent words: n_words_max * envs_per_block * 4][obs staging: envs_per_block * 41 * 4]
+// dynamic LDS layout: [hot_cap][ent words: n_words_max * envs_per_block * 4][obs staging: envs_per_block * 41 * 4][pad to 8]
+//                     [spill rows: envs_per_block * LDS_SPILL_BYTES][zoo blocks + grid edges]
+// spill row of an env (round 3): what the step kernel parks in LDS instead of scratch memory -- the eight ninja doubles that are
+// dead during the collision loops (64 B) and the DepenIO / DepenIOZ block handed to the out-of-line depenetration fallback
+constexpr int LDS_SPILL_BYTES = 208;   // 8 doubles | 8 ints | DepenIOZ (104 B, from byte 96)
+__host__ __device__ inline size_t lds_spill_offset(uint32_t hot_cap, int n_words_max, int envs_per_block) {
+    const size_t b = (size_t)hot_cap + (size_t)n_words_max * envs_per_block * 4 + (size_t)envs_per_block * 41 * 4;
+    return (b + 7) & ~(size_t)7;
+}
+__host__ __device__ inline size_t lds_zoo_offset(uint32_t hot_cap, int n_words_max, int envs_per_block) {
+    return lds_spill_offset(hot_cap, n_words_max, envs_per_block) + (size_t)envs_per_block * LDS_SPILL_BYTES;
+}
 inline size_t lds_bytes(uint32_t hot_cap, int n_words_max, int envs_per_block, int zoo_words = 0) {
-    size_t b = (size_t)hot_cap + (size_t)n_words_max * envs_per_block * 4 + (size_t)envs_per_block * 41 * 4;
-    b = (b + 7) & ~(size_t)7;
+    size_t b = lds_zoo_offset(hot_cap, n_words_max, envs_per_block);
     // zoo kernels add, per env: the zoo block and a private copy of the level's grid-edge bitmaps
     if (zoo_words) b += (size_t)envs_per_block * ((size_t)zoo_words * 8 + 2 * EDGE_WORDS_D * 4);
     return b;

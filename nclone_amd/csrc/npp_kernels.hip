@@ -75,11 +75,12 @@ struct Stamps { unsigned long long acc[N_STAMP]; unsigned long long t0; };
 
 struct Nj {
     double x, y, vx, vy, vxo, vyo, fnx, fny, cnx, cny;
-    double scx, scy;   // where the cached mine overlay of spatial_context was computed
-    int scvalid;
-    int state, airborn, airborn_old, walled, wn, jio, hor, jump, gjump, dslow;
-    int jbuf, fbuf, wbuf, lbuf, cause, timpact;
-    int jdur, fcount, ccount, pstate, fair, scf, frame, gold, doors, pcell;
+    // (where the cached mine overlay of spatial_context was computed lives in the F_SCX / F_SCY state planes only: the one place
+    // that reads or writes it is write_spatial_context, so the kernel does not carry it through the ticks)
+    // counters with a wide range stay plain ints (they saturate when stored, never wrap); everything with a handful of values is
+    // a bit field: two 32-bit storage units instead of twenty registers per lane.  The kernel is register-bound at two wavefronts
+    // per SIMD ("Registers and occupancy"), and these fields are dead weight inside the collision loops.
+    int fcount, ccount, fair, scf, frame, gold, doors;
     int work;   // depenetration iterations applied since the step began (npp_step_out.d_work; not part of the state)
     int fastord;   // bit 0: set after a Simulator.fast_reset -- the cell lists are in entity_dic order (nsim.py:124-140);
                    // bit 1: the level was assigned and no Simulator.reset has run since (the state of a fresh NppEnvironment after
@@ -87,6 +88,9 @@ struct Nj {
                    // first reset() finds _last_reset_map_name None and reloads the map (npp_environment.py:518-557);
                    // bits 2-14: episode counter mod 8192, bumped by every reset (the reachability kernel drops the env's per-episode
                    // path-distance cache when it changes: reachability_mixin.py:67-70 clears the calculator at every reset)
+    unsigned state : 4, airborn : 1, airborn_old : 1, walled : 1, jio : 1, jump : 1, gjump : 1, dslow : 1;
+    int wn : 2, hor : 2, jbuf : 4, fbuf : 4, wbuf : 4, lbuf : 4;            // wn, hor in {-1, 0, 1}; buffers in -1 .. 5
+    unsigned cause : 2, timpact : 1, jdur : 7, pstate : 4, scvalid : 1, pcell : 11;   // jdur <= 46, pcell < 1100
 };
 DEV int next_episode(int fastord) { return (((fastord >> 2) + 1) & 0x1fff) << 2; }
 
@@ -103,6 +107,8 @@ struct Lv {
     uint32_t n_think, n_words;
     int obs_switch, obs_door;
     double spawn_x, spawn_y, sw_x, sw_y, door_x, door_y;
+    double *spill;   // the env's LDS spill row (npp_internal.hpp: LDS_SPILL_BYTES): doubles [0, 8) parked ninja doubles, [8, 12) parked
+                     // ninja counters (as ints), [12, ..) DepenIO
 };
 
 // the three collision tables, passed BY VALUE to the out-of-line fallbacks so that nothing the hot loop touches
@@ -152,7 +158,6 @@ DEV void load_state(const KernelArgs &a, int e, Nj &n) {
     n.vxo = a.f64[F_VXO * N + e]; n.vyo = a.f64[F_VYO * N + e];
     n.fnx = a.f64[F_FNX * N + e]; n.fny = a.f64[F_FNY * N + e];
     n.cnx = a.f64[F_CNX * N + e]; n.cny = a.f64[F_CNY * N + e];
-    n.scx = a.f64[F_SCX * N + e]; n.scy = a.f64[F_SCY * N + e];
     uint32_t A = a.u32[U_A * N + e], B = a.u32[U_B * N + e], C = a.u32[U_C * N + e], D = a.u32[U_D * N + e],
              E = a.u32[U_E * N + e];
     n.state = A & 15; n.airborn = (A >> 4) & 1; n.airborn_old = (A >> 5) & 1; n.walled = (A >> 6) & 1;
@@ -178,7 +183,6 @@ DEV void store_state(const KernelArgs &a, int e, const Nj &n) {
     a.f64[F_VXO * N + e] = n.vxo; a.f64[F_VYO * N + e] = n.vyo;
     a.f64[F_FNX * N + e] = n.fnx; a.f64[F_FNY * N + e] = n.fny;
     a.f64[F_CNX * N + e] = n.cnx; a.f64[F_CNY * N + e] = n.cny;
-    a.f64[F_SCX * N + e] = n.scx; a.f64[F_SCY * N + e] = n.scy;
     uint32_t A = (uint32_t)n.state | (n.airborn << 4) | (n.airborn_old << 5) | (n.walled << 6) | ((n.wn + 1) << 7) |
                  (n.jio << 9) | ((n.hor + 1) << 10) | (n.jump << 12) | (n.gjump << 13) | (n.dslow << 14) |
                  ((n.jbuf + 1) << 15) | ((n.fbuf + 1) << 18) | ((n.wbuf + 1) << 21) | ((n.lbuf + 1) << 24) |
@@ -199,7 +203,7 @@ DEV void spawn_state(const Lv &lv, Nj &n) {
     n.gjump = 0; n.dslow = 0; n.jbuf = -1; n.fbuf = -1; n.wbuf = -1; n.lbuf = -1; n.cause = 0; n.timpact = 0;
     n.jdur = 0; n.fcount = 0; n.ccount = 0; n.pstate = 0; n.fair = 0; n.scf = 0; n.frame = 0; n.gold = 0; n.doors = 0;
     n.pcell = cell_coord(n.x, 43) * 25 + cell_coord(n.y, 24);
-    n.scx = 0; n.scy = 0; n.scvalid = 0;   // reset_mine_overlay_cache (npp_environment.py:569-571)
+    n.scvalid = 0;   // reset_mine_overlay_cache (npp_environment.py:569-571); the anchor planes are rewritten with the next overlay
     n.fastord = 0; n.work = 0;
 }
 
@@ -838,8 +842,11 @@ DEV void crush_add(DepenIOZ &io, double dx, double dy, double len) { io.xcr += d
     }
 
 // LDS-table fallback of the whole loop (rare: the query left the gathered region)
+// `slot`: the env's LDS spill row holds the IO block (every lane of the group carries the same values; lane 0 wrote them): a struct
+// of this size would travel through scratch memory as a by-value argument / return value.
 template <int G, typename IO>
-__device__ __noinline__ IO depen_generic(TileRefs lv, int r, double gx0, double gy0, double gx1, double gy1, IO io) {
+__device__ __noinline__ void depen_generic(TileRefs lv, int r, double gx0, double gy0, double gx1, double gy1, IO *slot) {
+    IO io = *slot;
     const int c0x = cell_coord(gx0, 43), c1x = cell_coord(gx1, 43), c0y = cell_coord(gy0, 24), c1y = cell_coord(gy1, 24);
     for (int it = 0; it < 32; it++) {
         Best m;
@@ -866,7 +873,7 @@ __device__ __noinline__ IO depen_generic(TileRefs lv, int r, double gx0, double 
         group_argmin<G>(m);
         NPP_DEPEN_STEP(io, m, break)
     }
-    return io;
+    if (r == 0) *slot = io;
 }
 
 // Ninja.collide_vs_tiles (ninja.py:269-379).  Returns the number of depenetrations applied.
@@ -970,7 +977,11 @@ DEV int collide_vs_tiles(const Lv &lv, int r, Nj &n, const Cand<K> &cd, double x
 #ifdef NPP_STAMPS
         st.acc[11] += 1;   // substeps that took the LDS fallback
 #endif
-        io = depen_generic<G, IO>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, gx0, gy0, gx1, gy1, io);
+        IO *slot = reinterpret_cast<IO *>(lv.spill + 12);
+        static_assert(sizeof(IO) + 96 <= LDS_SPILL_BYTES, "spill row too small for the depenetration block");
+        if (r == 0) *slot = io;
+        depen_generic<G, IO>(TileRefs{lv.seg_start, lv.segs, lv.bounds}, r, gx0, gy0, gx1, gy1, slot);
+        io = *slot;
     }
     n.x = io.x; n.y = io.y; n.vx = io.vx; n.vy = io.vy;
     fnsx = io.fnsx; fnsy = io.fnsy; cnsx = io.cnsx; cnsy = io.cnsy;
@@ -1314,6 +1325,9 @@ template <int G, bool ZOO, int V>
 DEV void sim_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb, int hor, int jump, int n_ent STAMP_ARG) {
     constexpr int K = VariantK<G, ZOO, V>::value;
     STAMP_INIT;
+    // the inputs are the same for the four ticks of a Gymnasium step: without this the compiler hoists products such as
+    // GROUND_ACCEL * hor out of the tick loop and carries them (in scratch memory, as it turned out) through every tick
+    asm volatile("" : "+v"(hor), "+v"(jump));
     n.frame += 1;
     n.hor = hor;
     n.jump = jump;
@@ -1340,6 +1354,19 @@ DEV void sim_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb, int hor,
         if (zoo) zoo_pre_collision<G>(lv, z, r, n, zt);
         // candidate segments for every query of this tick: cells touched by the path inflated by the largest
         // query radius (10.1) plus slack for depenetration drift
+        // Eight ninja doubles are dead weight from here to post_collision (nothing in the substeps reads the previous speeds, the
+        // normalised floor / ceiling normals or the spatial-context anchor): parked in the env's LDS spill row instead of letting
+        // the register allocator push them to scratch memory (every lane of the group holds the same values; lane 0 writes, all
+        // read back).  Plain kernels only: the zoo's physical collisions read some of them.
+        if constexpr (!ZOO) {
+            if (r == 0) {
+                double *sp = lv.spill;
+                sp[0] = n.vxo; sp[1] = n.vyo; sp[2] = n.fnx; sp[3] = n.fny; sp[4] = n.cnx; sp[5] = n.cny;
+                int *ip = reinterpret_cast<int *>(sp + 8);   // and six counters nobody looks at before post_collision / think
+                ip[0] = n.fair; ip[1] = n.scf; ip[2] = n.frame; ip[3] = n.gold; ip[4] = n.doors; ip[5] = n.fastord;
+            }
+            asm volatile("" ::: "memory");
+        }
         Cand<K> cd;
         {
             const double pad = NINJA_RADIUS + 2.2;
@@ -1364,6 +1391,13 @@ DEV void sim_tick(const Lv &lv, const Zoo &z, int r, Nj &n, EntBits eb, int hor,
             if (!(zoo && zt.phys_near) && applied == 0 && n.x == xb && n.y == yb) break;
         }
         STAMP(4);
+        if constexpr (!ZOO) {
+            asm volatile("" ::: "memory");
+            const double *sp = lv.spill;
+            n.vxo = sp[0]; n.vyo = sp[1]; n.fnx = sp[2]; n.fny = sp[3]; n.cnx = sp[4]; n.cny = sp[5];
+            const int *ip = reinterpret_cast<const int *>(sp + 8);
+            n.fair = ip[0]; n.scf = ip[1]; n.frame = ip[2]; n.gold = ip[3]; n.doors = ip[4]; n.fastord = ip[5];
+        }
         post_collision<G, K, ZOO>(lv, z, r, n, cd, eb, fnsx, fnsy, cnsx, cnsy, xold, yold, zt);
         STAMP(5);
     }
@@ -1466,7 +1500,8 @@ DEV void write_spatial_context(const KernelArgs &a, const LevelHdr &H, Nj &n, En
     }
     bool hit = false;
     if (n.scvalid) {
-        double dx = n.x - n.scx, dy = n.y - n.scy;
+        const size_t N = (size_t)a.n;
+        double dx = n.x - a.f64[F_SCX * N + env], dy = n.y - a.f64[F_SCY * N + env];
         hit = dx * dx + dy * dy < 144.0;
     }
     if (hit) {
@@ -1543,7 +1578,8 @@ DEV void write_spatial_context(const KernelArgs &a, const LevelHdr &H, Nj &n, En
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) { cache[6 * k + jj] = f[jj]; out[64 + 6 * k + jj] = f[jj]; }
     }
-    n.scvalid = 1; n.scx = n.x; n.scy = n.y;
+    n.scvalid = 1;
+    if (r == 0) { a.f64[F_SCX * (size_t)a.n + env] = n.x; a.f64[F_SCY * (size_t)a.n + env] = n.y; }
 }
 
 // contiguous workgroup store of per-env rows of `width` 4-byte words staged at stage[env_in_block * width + k]
@@ -1559,6 +1595,7 @@ template <bool ZOO>
 DEV void episode_reset(const KernelArgs &a, const LevelHdr &H, Lv &lv, Zoo &z, Nj &n, EntBits eb, int nw, int r, int G) {
     const bool fast = a.fast_reset && !(n.fastord & 2);   // the first reset after a level assignment is a Simulator.reset
     const int episode = next_episode(n.fastord);
+    lv.spawn_x = H.spawn_x; lv.spawn_y = H.spawn_y;
     spawn_state(lv, n);
     n.fastord = episode;
     if (fast) {
@@ -1609,7 +1646,10 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     eb.w = ew + eib;
     eb.stride = epb;
 
-    const int lvl = a.env_level[e];
+    // LDS_LEVEL: the host guarantees that every env of the workgroup plays ONE level, so the level header and everything read
+    // from it (table pointers, spawn / switch / door coordinates) is wavefront-uniform: scalar loads into SGPRs instead of ~36
+    // VGPRs per lane that stay live for the whole kernel
+    const int lvl = LDS_LEVEL ? __builtin_amdgcn_readfirstlane(a.env_level[e]) : a.env_level[e];
     const LevelHdr &H = a.hdr[lvl];
     Lv lv;
     const unsigned char *hot = a.blob + H.off_hot;
@@ -1631,15 +1671,18 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     lv.init_words = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
     lv.n_think = H.n_think; lv.n_words = H.n_words;
     lv.obs_switch = H.obs_switch; lv.obs_door = H.obs_door;
-    lv.spawn_x = H.spawn_x; lv.spawn_y = H.spawn_y;
-    lv.sw_x = H.sw_x; lv.sw_y = H.sw_y; lv.door_x = H.door_x; lv.door_y = H.door_y;
+    // spawn / switch / door coordinates: the plain kernels read them from the level header where they are used (episode reset,
+    // observation rows) -- loaded here they sat in 12 VGPRs through every tick; the zoo kernels may override them per env
+    lv.spawn_x = 0; lv.spawn_y = 0; lv.sw_x = 0; lv.sw_y = 0; lv.door_x = 0; lv.door_y = 0;
+    if constexpr (ZOO) { lv.sw_x = H.sw_x; lv.sw_y = H.sw_y; lv.door_x = H.door_x; lv.door_y = H.door_y; }
+    lv.spill = reinterpret_cast<double *>(smem + lds_spill_offset(LDS_LEVEL ? a.lds_hot_cap : 0u, a.n_words_max, epb)) +
+               (size_t)eib * (LDS_SPILL_BYTES / 8);
 
     // entity zoo: this env's block and a private copy of its level's grid edges live in LDS behind the staging rows
     Zoo z;
     z.on = false; z.blk = nullptr; z.edges = nullptr; z.n_mov = 0; z.n_door = 0; z.n_balls = 0;
     if constexpr (ZOO) {
-        size_t zoff = (size_t)(LDS_LEVEL ? a.lds_hot_cap : 0u) + (size_t)a.n_words_max * epb * 4 + (size_t)epb * 41 * 4;
-        zoff = (zoff + 7) & ~(size_t)7;
+        const size_t zoff = lds_zoo_offset(LDS_LEVEL ? a.lds_hot_cap : 0u, a.n_words_max, epb);
         z.blk = reinterpret_cast<double *>(smem + zoff) + (size_t)eib * a.zoo_words;
         z.edges = reinterpret_cast<uint32_t *>(smem + zoff + (size_t)epb * a.zoo_words * 8) + (size_t)eib * (2 * EDGE_WORDS_D);
         const uint32_t ovr = reinterpret_cast<const uint32_t *>(a.zoo + (size_t)e * a.zoo_words + 3)[0];
@@ -1693,7 +1736,6 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     __syncthreads();
 
     STAMP(0);
-    const int limit = a.trunc_limit[e];
     uint32_t flags = 0;
     int executed = 0;
     float reward = 0.f;
@@ -1742,7 +1784,8 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         if (n.cause == 1) flags |= 16u;
         if (n.cause == 2) flags |= 32u;
         done = (flags & 3u) != 0;
-        if (stepping && !done && n.frame >= limit) { flags |= 8u; done = true; }   // truncation_checker.py:46-77
+        // (the limit is read where it is used, here and in the observation rows, rather than held in a register through the ticks)
+        if (stepping && !done && n.frame >= a.trunc_limit[e]) { flags |= 8u; done = true; }   // truncation_checker.py:46-77
         // sparse terminal reward: completion 200, switch 100, death -30, scaled by 0.1 (reward_constants.py:71,115,148,212)
         if (flags & 1u) reward += 20.f;
         if (flags & 2u) reward -= 3.f;
@@ -1768,7 +1811,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         if (pass == 1 && do_reset) episode_reset<ZOO>(a, H, lv, z, n, eb, nw, r, G);
         float *gdst = pass == 0 ? a.out.terminal_state : a.out.game_state;
         if (gdst) {
-            if (r == 0) write_game_state(n, limit, reinterpret_cast<float *>(stage) + eib * 41);
+            if (r == 0) write_game_state(n, a.trunc_limit[e], reinterpret_cast<float *>(stage) + eib * 41);
             __syncthreads();
             if (pass == 1) {
                 block_store_rows(stage, reinterpret_cast<uint32_t *>(gdst + (size_t)env0 * 41), 41, n_valid);
@@ -1784,8 +1827,8 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
         if (r == 0) {
             float *row = reinterpret_cast<float *>(stage) + eib * 6;
             row[0] = (float)(n.x / 1056.0); row[1] = (float)(n.y / 600.0);
-            row[2] = (float)(lv.sw_x / 1056.0); row[3] = (float)(lv.sw_y / 600.0);
-            row[4] = (float)(lv.door_x / 1056.0); row[5] = (float)(lv.door_y / 600.0);
+            row[2] = (float)((ZOO ? lv.sw_x : H.sw_x) / 1056.0); row[3] = (float)((ZOO ? lv.sw_y : H.sw_y) / 600.0);
+            row[4] = (float)((ZOO ? lv.door_x : H.door_x) / 1056.0); row[5] = (float)((ZOO ? lv.door_y : H.door_y) / 600.0);
         }
         __syncthreads();
         block_store_rows(stage, reinterpret_cast<uint32_t *>(a.out.entity_pos + (size_t)env0 * 6), 6, n_valid);
@@ -1793,7 +1836,8 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     }
     if (a.out.positions && writer) {   // pass-through scalars player_x/y, switch_x/y, exit_door_x/y (unrounded)
         double *row = a.out.positions + (size_t)env * 6;
-        row[0] = n.x; row[1] = n.y; row[2] = lv.sw_x; row[3] = lv.sw_y; row[4] = lv.door_x; row[5] = lv.door_y;
+        row[0] = n.x; row[1] = n.y;
+        row[2] = ZOO ? lv.sw_x : H.sw_x; row[3] = ZOO ? lv.sw_y : H.sw_y; row[4] = ZOO ? lv.door_x : H.door_x; row[5] = ZOO ? lv.door_y : H.door_y;
     }
     if (a.out.spatial_context) write_spatial_context<G>(a, H, n, eb, env, r, valid);
     if (a.out.action_mask && writer) {
