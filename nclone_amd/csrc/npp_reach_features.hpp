@@ -67,66 +67,98 @@ NPP_HD inline int reach_order_key(int id) {
 
 NPP_HD inline double reach_floor(double v) { return floor(v); }
 
-// find_ninja_node (pathfinding_utils.py:1331-1497).  goal_node < 0: no goal node given (closest overlapping node wins);
-// otherwise the overlapping node with the smallest cached distance to goal `g` wins (Euclidean to goal_node when not cached,
-// or always when g < 0: the call carries no goal id).
-NPP_HD inline int reach_find_ninja_node(const ReachTabs &T, double px, double py, int goal_node, int g) {
+// find_ninja_node (pathfinding_utils.py:1331-1497) in two parts, because one feature vector calls it up to five times at the same
+// position: reach_near() gathers the nodes the ninja overlaps ONCE (with every table read of the gather issued up front instead
+// of one dependent load per lattice cell -- the device kernel is bound by exactly these chains), reach_pick() applies a call's rule.
+struct ReachNear {
+    int n;            // overlapping nodes (0 .. 4), in the iteration order of the reference's adjacency dict
+    int id[4];
+    double d2[4];     // squared distance to the ninja
+    int fallback;     // n == 0: the first node in dict order inside the 24-px box around the ninja, -1 = none
+};
+
+NPP_HD inline ReachNear reach_near(const ReachTabs &T, double px, double py) {
     const double nx = px - 24.0, ny = py - 24.0;
     const unsigned char *in = T.in();
-    int cand[4], nc = 0;
-    double cd[4];
-    const int i0 = (int)ceil((nx - 10.0 - 6.0) / 12.0), i1 = (int)reach_floor((nx + 10.0 - 6.0) / 12.0);
-    const int j0 = (int)ceil((ny - 10.0 - 6.0) / 12.0), j1 = (int)reach_floor((ny + 10.0 - 6.0) / 12.0);
-    for (int i = i0; i <= i1; i++)
-        for (int j = j0; j <= j1; j++) {
-            if (i < 0 || i >= RW || j < 0 || j >= RH) continue;
-            const int id = i * RH + j;
-            if (!in[id]) continue;
-            const double dx = (6 + 12 * i) - nx, dy = (6 + 12 * j) - ny, d2 = dx * dx + dy * dy;
-            if (d2 <= 100.0 && nc < 4) { cand[nc] = id; cd[nc] = d2; nc++; }
-        }
-    // dict order
-    for (int a = 1; a < nc; a++)
-        for (int b = a; b > 0 && reach_order_key(cand[b]) < reach_order_key(cand[b - 1]); b--) {
-            const int t = cand[b]; cand[b] = cand[b - 1]; cand[b - 1] = t;
-            const double u = cd[b]; cd[b] = cd[b - 1]; cd[b - 1] = u;
-        }
-    if (nc > 0) {
-        if (goal_node >= 0 && nc > 1) {
-            int best = -1;
-            double bd = INFINITY;
-            const double gx = reach_node_x(goal_node), gy = reach_node_y(goal_node);
-            for (int k = 0; k < nc; k++) {
-                double d = g >= 0 ? T.dist(g)[cand[k]] : INFINITY;   // g < 0: no goal id -> Euclidean (the miss branch)
-                if (d == INFINITY) {
-                    const double ex = gx - reach_node_x(cand[k]), ey = gy - reach_node_y(cand[k]);
-                    d = sqrt(ex * ex + ey * ey);   // ((gx - nx) ** 2 + (gy - ny) ** 2) ** 0.5 on integers
-                }
-                if (d < bd) { bd = d; best = cand[k]; }
-            }
-            if (best >= 0) return best;
-        }
-        int best = cand[0];
-        double bd = cd[0];
-        for (int k = 1; k < nc; k++)
-            if (cd[k] < bd) { bd = cd[k]; best = cand[k]; }   // stable sort by distance: the first minimum in dict order
-        return best;
+    ReachNear N;
+    N.n = 0; N.fallback = -1;
+    // nodes within 10 px: at most two lattice indices per axis (the spacing is 12)
+    const int i0 = (int)ceil((nx - 10.0 - 6.0) / 12.0), j0 = (int)ceil((ny - 10.0 - 6.0) / 12.0);
+    const int i1 = (int)reach_floor((nx + 10.0 - 6.0) / 12.0), j1 = (int)reach_floor((ny + 10.0 - 6.0) / 12.0);
+    int cid[4];
+    unsigned char present[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // (i0, j0) (i0, j0 + 1) (i0 + 1, j0) (i0 + 1, j0 + 1): the order of the reference's double loop
+        const int i = i0 + (k >> 1), j = j0 + (k & 1);
+        const bool ok = i <= i1 && j <= j1 && i >= 0 && i < RW && j >= 0 && j < RH;
+        cid[k] = ok ? i * RH + j : -1;
+        present[k] = in[ok ? cid[k] : 0];   // unconditional, independent loads
     }
-    // fallback: the first node in dict order with |x + 24 - px| < 24 and |y + 24 - py| < 24
-    int best = -1, bk = 0x7fffffff;
-    const int a0 = (int)reach_floor((nx - 24.0 - 6.0) / 12.0), a1 = (int)ceil((nx + 24.0 - 6.0) / 12.0);
-    const int b0 = (int)reach_floor((ny - 24.0 - 6.0) / 12.0), b1 = (int)ceil((ny + 24.0 - 6.0) / 12.0);
-    for (int i = a0; i <= a1; i++)
-        for (int j = b0; j <= b1; j++) {
-            if (i < 0 || i >= RW || j < 0 || j >= RH) continue;
-            const int id = i * RH + j;
-            if (!in[id]) continue;
-            if (fabs((6 + 12 * i) + 24.0 - px) < 24.0 && fabs((6 + 12 * j) + 24.0 - py) < 24.0) {
-                const int k = reach_order_key(id);
-                if (k < bk) { bk = k; best = id; }
-            }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (cid[k] < 0 || !present[k]) continue;
+        const double dx = reach_node_x(cid[k]) - nx, dy = reach_node_y(cid[k]) - ny, d2 = dx * dx + dy * dy;
+        if (d2 <= 100.0) { N.id[N.n] = cid[k]; N.d2[N.n] = d2; N.n++; }
+    }
+    // dict order
+    for (int a = 1; a < N.n; a++)
+        for (int b = a; b > 0 && reach_order_key(N.id[b]) < reach_order_key(N.id[b - 1]); b--) {
+            const int t = N.id[b]; N.id[b] = N.id[b - 1]; N.id[b - 1] = t;
+            const double u = N.d2[b]; N.d2[b] = N.d2[b - 1]; N.d2[b - 1] = u;
         }
+    if (N.n == 0) {
+        // fallback: the first node in dict order with |x + 24 - px| < 24 and |y + 24 - py| < 24
+        int best = -1, bk = 0x7fffffff;
+        const int a0 = (int)reach_floor((nx - 24.0 - 6.0) / 12.0), a1 = (int)ceil((nx + 24.0 - 6.0) / 12.0);
+        const int b0 = (int)reach_floor((ny - 24.0 - 6.0) / 12.0), b1 = (int)ceil((ny + 24.0 - 6.0) / 12.0);
+        for (int i = a0; i <= a1; i++)
+            for (int j = b0; j <= b1; j++) {
+                if (i < 0 || i >= RW || j < 0 || j >= RH) continue;
+                const int id = i * RH + j;
+                if (!in[id]) continue;
+                if (fabs((6 + 12 * i) + 24.0 - px) < 24.0 && fabs((6 + 12 * j) + 24.0 - py) < 24.0) {
+                    const int k = reach_order_key(id);
+                    if (k < bk) { bk = k; best = id; }
+                }
+            }
+        N.fallback = best;
+    }
+    return N;
+}
+
+// goal_node < 0: no goal node given (closest overlapping node wins); otherwise the overlapping node with the smallest cached
+// distance to goal `g` wins (Euclidean to goal_node when not cached, or always when g < 0: the call carries no goal id).
+NPP_HD inline int reach_pick(const ReachTabs &T, const ReachNear &N, int goal_node, int g) {
+    if (N.n == 0) return N.fallback;
+    if (goal_node >= 0 && N.n > 1) {
+        double dg[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) dg[k] = (g >= 0 && k < N.n) ? T.dist(g)[N.id[k]] : INFINITY;   // independent loads
+        int best = -1;
+        double bd = INFINITY;
+        const double gx = reach_node_x(goal_node), gy = reach_node_y(goal_node);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= N.n) break;
+            double d = dg[k];
+            if (d == INFINITY) {
+                const double ex = gx - reach_node_x(N.id[k]), ey = gy - reach_node_y(N.id[k]);
+                d = sqrt(ex * ex + ey * ey);   // ((gx - nx) ** 2 + (gy - ny) ** 2) ** 0.5 on integers
+            }
+            if (d < bd) { bd = d; best = N.id[k]; }
+        }
+        if (best >= 0) return best;
+    }
+    int best = N.id[0];
+    double bd = N.d2[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (k < N.n && N.d2[k] < bd) { bd = N.d2[k]; best = N.id[k]; }   // stable sort by distance: the first minimum in dict order
     return best;
+}
+
+NPP_HD inline int reach_find_ninja_node(const ReachTabs &T, double px, double py, int goal_node, int g) {
+    return reach_pick(T, reach_near(T, px, py), goal_node, g);
 }
 
 // find_ninja_node with search_radius_override = R, or (R < 0) the "ANY closest node in the entire adjacency graph" loop that
@@ -156,7 +188,7 @@ NPP_HD inline int reach_scan_node(const ReachTabs &T, double px, double py, doub
 // The miss branch for the exit door (path_distance_calculator.py:949-960 and 1218-1485): the raw cost of the calculator's
 // per-episode dictionary for the ninja's cell, computed and stored on the first query of the cell.  `peek`: look the entry up
 // without creating it (the switch's query, which only ever READS the shared key); returns NaN when absent.
-NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, double px, double py, ReachMiss *M, bool peek, bool *miss) {
+NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, const ReachNear &N, double px, double py, ReachMiss *M, bool peek, bool *miss) {
     int cx = reach_cell24(px), cy = reach_cell24(py);
     cx = cx < 0 ? 0 : (cx > 43 ? 43 : cx);
     cy = cy < 0 ? 0 : (cy > 24 ? 24 : cy);
@@ -164,7 +196,7 @@ NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, double px, double p
     if (M && M->stamp[cell] == M->epoch) return M->raw[cell];
     if (peek) return NAN;
     // temp start node: find_ninja_node, then the 48 / 150 px retries, then any closest node
-    int t = reach_find_ninja_node(T, px, py, -1, 0);
+    int t = reach_pick(T, N, -1, 0);
     if (t < 0) t = reach_scan_node(T, px, py, 48.0, -1);
     if (t < 0) t = reach_scan_node(T, px, py, 150.0, -1);
     if (t < 0) t = reach_scan_node(T, px, py, -1.0, -1);
@@ -175,7 +207,7 @@ NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, double px, double p
             const int c = T.H->cand[k];
             // the final start node: get_distance still carries the INFERRED goal id ("switch") at this point, so among several overlapping
             // nodes the one with the smallest cached distance to the switch wins (Euclidean to the goal node when it has none)
-            int s = reach_find_ninja_node(T, px, py, c, 0);
+            int s = reach_pick(T, N, c, 0);
             if (s < 0) s = reach_scan_node(T, px, py, 48.0, c);
             if (s < 0) s = reach_scan_node(T, px, py, 150.0, c);
             if (s < 0) s = reach_scan_node(T, px, py, -1.0, c);
@@ -191,11 +223,11 @@ NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, double px, double p
 
 // get_distance / get_geometric_distance on the level-cache path (they return the same number there).  g: 0 exit switch,
 // 1 exit door.  Returns +inf when unreachable; sets *miss when the reference would leave the level-cache path.
-NPP_HD inline double reach_level_distance(const ReachTabs &T, double px, double py, int g, double entity_radius, bool *miss) {
+NPP_HD inline double reach_level_distance(const ReachTabs &T, const ReachNear &N, double px, double py, int g, double entity_radius, bool *miss) {
     const ReachHdr &H = *T.H;
     const double combined = 10.0 + entity_radius;
     const int gid = g == 1 ? H.exit_gid : 0;   // which goal's tables the reference reads (goal-id inference, see ReachHdr)
-    const int sn = reach_find_ninja_node(T, px, py, H.goal_node[2 + g], gid);   // goal node of get_distance: thresholds 16 / 22, then 32
+    const int sn = reach_pick(T, N, H.goal_node[2 + g], gid);   // goal node of get_distance: thresholds 16 / 22, then 32
     if (sn < 0) { *miss = true; return INFINITY; }
     const double cached = T.dist(gid)[sn];
     if (cached == INFINITY) { *miss = true; return INFINITY; }
@@ -217,8 +249,8 @@ NPP_HD inline double reach_level_distance(const ReachTabs &T, double px, double 
 // get_distance (path_distance_calculator.py:847-1485).  g: 0 exit switch, 1 exit door.  Returns +inf when unreachable; sets *miss
 // when the reference would run a part of its miss branch that is not tabulated.  geometric = true: get_geometric_distance
 // (path_distance_calculator.py:1487-1975), which never looks at the per-episode dictionary.
-NPP_HD inline double reach_goal_distance(const ReachTabs &T, double px, double py, int g, double entity_radius, ReachMiss *M, bool geometric,
-                                         bool *miss) {
+NPP_HD inline double reach_goal_distance(const ReachTabs &T, const ReachNear &N, double px, double py, int g, double entity_radius, ReachMiss *M,
+                                         bool geometric, bool *miss) {
     const ReachHdr &H = *T.H;
     const int gx = H.goal_x[g], gy = H.goal_y[g];
     if (gx == 0 && gy == 0) return INFINITY;
@@ -228,14 +260,14 @@ NPP_HD inline double reach_goal_distance(const ReachTabs &T, double px, double p
     if (H.miss_exit && !geometric) {
         // the per-episode dictionary comes first; its key holds the goal's CELL, so a switch in the door's cell reads the door's entry
         if (g == 1 || H.sw_alias) {
-            const double raw = reach_exit_miss_raw(T, px, py, M, g == 0, miss);
+            const double raw = reach_exit_miss_raw(T, N, px, py, M, g == 0, miss);
             if (raw == raw) {
                 const double t = raw - combined;
                 return t > 0.0 ? t : 0.0;   // max(0.0, inf - r) = inf
             }
         }
     }
-    return reach_level_distance(T, px, py, g, entity_radius, miss);
+    return reach_level_distance(T, N, px, py, g, entity_radius, miss);
 }
 
 NPP_HD inline float reach_clip01(double v) { return (float)(v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v)); }
@@ -249,14 +281,15 @@ NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int t
     bool miss = false;
     out[0] = H.f0;
     const double area = H.area_scale;
+    const ReachNear N = reach_near(T, px, py);   // the nodes the ninja overlaps: shared by every node selection below
     double d_sw = INFINITY, d_ex = INFINITY;
-    if (H.sw_valid) d_sw = reach_goal_distance(T, px, py, 0, 6.0, M, false, &miss);
+    if (H.sw_valid) d_sw = reach_goal_distance(T, N, px, py, 0, 6.0, M, false, &miss);
     if (d_sw != INFINITY) out[1] = reach_clip01(1.0 - d_sw / area);
     else if (H.ex_valid) {   // third priority of the "next objective" ladder: the exit door (no locked-door switches reach here)
-        const double d = reach_goal_distance(T, px, py, 1, 12.0, M, false, &miss);
+        const double d = reach_goal_distance(T, N, px, py, 1, 12.0, M, false, &miss);
         if (d != INFINITY) out[1] = reach_clip01(1.0 - d / area);
     }
-    if (H.ex_valid) d_ex = reach_goal_distance(T, px, py, 1, 12.0, M, false, &miss);
+    if (H.ex_valid) d_ex = reach_goal_distance(T, N, px, py, 1, 12.0, M, false, &miss);
     if (d_ex != INFINITY) out[2] = reach_clip01(1.0 - d_ex / area);
     out[3] = H.exit_reachable;
     out[4] = d_sw != INFINITY ? reach_clip01(d_sw / area) : 1.f;
@@ -274,7 +307,7 @@ NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int t
     out[11] = total_mines > 0 ? (float)((double)deadly_mines / (double)total_mines) : 0.f;
     // out[12] = 0: the switch never reads as activated (see the header comment); current goal = "switch"
     int ninja_node = -1;
-    if (sw_dir) ninja_node = reach_find_ninja_node(T, px, py, -1, 0);
+    if (sw_dir) ninja_node = reach_pick(T, N, -1, 0);
     if (ninja_node >= 0) {
         const int nh = T.hop(0)[ninja_node];
         if (nh >= 0) {
@@ -307,7 +340,7 @@ NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int t
     }
     if (sw_dir) {   // 21: log-normalised physics cost / geometric distance.  Both come from the level cache's geometric table (ratio 1 ->
                     // 1/3) unless the switch query was answered from the per-episode dictionary (ReachHdr::sw_alias)
-        const double geo = (H.miss_exit && H.sw_alias) ? reach_goal_distance(T, px, py, 0, 6.0, M, true, &miss) : d_sw;
+        const double geo = (H.miss_exit && H.sw_alias) ? reach_goal_distance(T, N, px, py, 0, 6.0, M, true, &miss) : d_sw;
         if (geo != INFINITY && geo > 0.001) {
             double ratio = d_sw / geo;
             ratio = ratio > 0.1 ? ratio : 0.1;

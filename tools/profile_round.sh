@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): collects the rocprofv3 evidence for bench.py's roofline objects.
-#   tools/profile_round.sh TAG [extra bench.py args, e.g. --workload mines --player-frame]
+#   tools/profile_round.sh TAG [bench.py args: --workload c0 (default) | --workload mines --player-frame | --workload doors --full-obs]
 #   1. --kernel-trace --stats        -> per-kernel average duration (must agree with bench.py's HIP-event figure)
 #   2. --pmc FETCH_SIZE / WRITE_SIZE  -> HBM traffic, one counter per pass (TCC slots: MI355X_MICROARCH.md)
 #   3. --pmc SQ_* counters            -> instruction mix / lane utilisation
@@ -12,7 +12,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 300 --warmup 100 --no-cpu-baseline --async-streams 0 --open-loop-chunk 0 $*"
+ARGS=${*:---workload c0}
+BENCH="python3 $ROOT/bench.py --steps 300 --warmup 100 --no-cpu-baseline --async-streams 0 --open-loop-chunk 0 $ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1

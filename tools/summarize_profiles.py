@@ -119,6 +119,33 @@ def main():
                                  "write_bytes_per_launch": None if ws is None else ws * 1024}
         if fs is not None and ws is not None:
             out["render_traffic"]["hbm_bytes_per_launch"] = fs * 2048 + ws * 1024
+    # every kernel of ours in the run (round 3: the config-5 profile holds five): timed-region duration from the kernel trace and HBM
+    # traffic from the two PMC passes, per launch
+    by_kernel = {}
+    if kt:
+        rows_all = list(csv.DictReader(open(kt)))
+        for key, pat in (("step", "npp_step_kernel"), ("player_frame", "npp_render_kernel"), ("global_view", "npp_global_view_kernel"),
+                         ("reachability", "npp_reach_kernel"), ("switch_states", "npp_switch_states_kernel")):
+            rr = [r for r in rows_all if pat in r["Kernel_Name"]]
+            if not rr:
+                continue
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rr[-TIMED:]]
+            e = {"launches": len(d), "timed_region_avg_ns": sum(d) / len(d), "kernel": rr[-1]["Kernel_Name"][:120],
+                 "arch_vgpr": rr[-1].get("VGPR_Count"), "agpr": rr[-1].get("Accum_VGPR_Count"),
+                 "scratch_bytes_per_lane": rr[-1].get("Scratch_Size"), "lds_bytes_per_workgroup": rr[-1].get("LDS_Block_Size")}
+            t = {}
+            for name in ("fetch", "write"):
+                cc = find(os.path.join(src, name), "*counter_collection.csv")
+                if cc:
+                    t.update(counter_means(cc, pat, last=TIMED))
+            fs = t.get("FETCH_SIZE", {}).get("mean_per_dispatch")
+            ws = t.get("WRITE_SIZE", {}).get("mean_per_dispatch")
+            if fs is not None and ws is not None:
+                e.update({"read_bytes_per_launch_raw": fs * 1024, "read_bytes_per_launch_x2": fs * 2048, "write_bytes_per_launch": ws * 1024,
+                          "hbm_bytes_per_launch": fs * 2048 + ws * 1024})
+            by_kernel[key] = e
+    if by_kernel:
+        out["by_kernel"] = by_kernel
     sq = find(os.path.join(src, "sq"), "*counter_collection.csv")
     if sq:
         out["sq"] = counter_means(sq, last=TIMED)
