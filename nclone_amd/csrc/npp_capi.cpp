@@ -66,6 +66,10 @@ struct npp_handle_s {
     int tune_count = 0;              // launches inside the current state
     bool tuned = false;
     std::vector<hipEvent_t> tune_ev;   // one (start, end) pair per measured launch: 2 * TUNE_WINDOW * windows
+    // cost-split launch (experiment, NPP_STEP_SPLIT = "percent:variant_heavy:variant_light"): the heaviest workgroups of the
+    // heavy-first order run as their own launch of another build variant on a second stream, joined by events
+    hipStream_t split_stream = nullptr;
+    hipEvent_t split_ev[2] = {nullptr, nullptr};
     long tune_since = 0;             // launches since the last decision
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
@@ -414,6 +418,7 @@ int npp_destroy(npp_handle h) {
     hipFree(h->d_gv_x); hipFree(h->d_gv_order); hipFree(h->d_gv_cost); hipFree(h->d_wg_order); hipFree(h->d_wg_cost); hipFree(h->d_pf_order); hipFree(h->d_pf_cost);
     for (auto &e : h->tune_ev)
         if (e) hipEventDestroy(e);
+    if (h->split_stream) { hipStreamDestroy(h->split_stream); hipEventDestroy(h->split_ev[0]); hipEventDestroy(h->split_ev[1]); }
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -832,6 +837,29 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
         h->step_launches++;
         a.wg_order = h->d_wg_order;
         a.wg_cost = h->d_wg_cost;
+    }
+    {   // cost-split launch (VERDICT r2 #3b; off unless NPP_STEP_SPLIT is set -- measured, no gain: DESIGN.md 4.1)
+        static const char *sp = std::getenv("NPP_STEP_SPLIT");
+        int pct = 0, vh = 0, vl = 1;
+        if (sp && std::sscanf(sp, "%d:%d:%d", &pct, &vh, &vl) == 3 && pct > 0 && pct < 100 && h->geo_g == 16 && !h->zoo_active && a.wg_order) {
+            const int epb = (64 / h->geo_g) * h->geo_wpb, blocks = (h->n + epb - 1) / epb;
+            const int heavy = std::max(1, blocks * pct / 100);
+            if (!h->split_stream) {
+                HIP_TRY(h, hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->split_ev[0], hipEventDisableTiming));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->split_ev[1], hipEventDisableTiming));
+            }
+            HIP_TRY(h, hipEventRecord(h->split_ev[0], h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->split_stream, h->split_ev[0], 0));
+            KernelArgs ah = a, al = a;
+            ah.variant = vh; ah.wg_first = 0; ah.wg_count = heavy;
+            al.variant = vl; al.wg_first = heavy; al.wg_count = blocks - heavy;
+            HIP_TRY(h, launch_step(ah, h->split_stream));
+            HIP_TRY(h, launch_step(al, h->stream));
+            HIP_TRY(h, hipEventRecord(h->split_ev[1], h->split_stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->split_ev[1], 0));
+            return NPP_OK;
+        }
     }
     int pair = -1;
     a.variant = tune_next(h, &pair);

@@ -116,6 +116,8 @@ struct KernelArgs {
     // workgroup steps, wg_cost[block] the shader clocks its last launch took (launch_cost_order rebuilds the order from the costs)
     const uint32_t *wg_order;
     uint32_t *wg_cost;
+    int wg_first, wg_count;   // cost-split launch (NPP_STEP_SPLIT): this launch covers entries [wg_first, wg_first + wg_count) of the
+                              // order; wg_count == 0 = the whole grid
     int variant;          // build variant of the G = 16 plain step kernels (npp_kernels.hip: VariantK); 0 everywhere else
     StepOut out;
 };

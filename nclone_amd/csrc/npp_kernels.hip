@@ -1632,7 +1632,7 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
     const int eib = wave * EPW + lane / G;     // env index inside the workgroup
     // heavy-first (npp_step): the workgroups whose envs iterated longest in an earlier launch are dispatched first, so that the
     // chain that decides the launch's duration starts at time zero instead of in the second residency round
-    const int blk = a.wg_order ? (int)a.wg_order[blockIdx.x] : (int)blockIdx.x;
+    const int blk = a.wg_order ? (int)a.wg_order[blockIdx.x + a.wg_first] : (int)blockIdx.x + a.wg_first;
     const unsigned long long wg_t0 = a.wg_cost ? __builtin_amdgcn_s_memtime() : 0ull;
     const int env0 = blk * epb;
     const int env = env0 + eib;
@@ -1961,7 +1961,7 @@ template <int G, bool Z, bool M>
 hipError_t launch_step_g(const KernelArgs &a, hipStream_t s) {
     const int wpb = a.waves_per_block;
     const int epb = (WAVE / G) * wpb;
-    const int blocks = (a.n + epb - 1) / epb;
+    const int blocks = a.wg_count > 0 ? a.wg_count : (a.n + epb - 1) / epb;
     const dim3 grid(blocks), block(WAVE * wpb);
     // zoo levels: LDS also holds the per-env zoo blocks
     const size_t lds = lds_bytes(a.lds_level ? a.lds_hot_cap : 0, a.n_words_max, epb, Z ? a.zoo_words : 0);

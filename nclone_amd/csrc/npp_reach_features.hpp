@@ -94,18 +94,26 @@ NPP_HD inline ReachNear reach_near(const ReachTabs &T, double px, double py) {
         cid[k] = ok ? i * RH + j : -1;
         present[k] = in[ok ? cid[k] : 0];   // unconditional, independent loads
     }
+    // the four slots stay at fixed positions (compile-time indices: registers, not scratch memory): a slot that does not qualify
+    // gets the largest key, a five-exchange sorting network puts the others first in dict order
+    int key[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (cid[k] < 0 || !present[k]) continue;
-        const double dx = reach_node_x(cid[k]) - nx, dy = reach_node_y(cid[k]) - ny, d2 = dx * dx + dy * dy;
-        if (d2 <= 100.0) { N.id[N.n] = cid[k]; N.d2[N.n] = d2; N.n++; }
+        const int idk = cid[k] < 0 ? 0 : cid[k];
+        const double dx = reach_node_x(idk) - nx, dy = reach_node_y(idk) - ny, d2 = dx * dx + dy * dy;
+        const bool ok = cid[k] >= 0 && present[k] && d2 <= 100.0;
+        N.id[k] = idk; N.d2[k] = d2;
+        key[k] = ok ? reach_order_key(idk) : 0x7fffffff;
+        N.n += ok ? 1 : 0;
     }
-    // dict order
-    for (int a = 1; a < N.n; a++)
-        for (int b = a; b > 0 && reach_order_key(N.id[b]) < reach_order_key(N.id[b - 1]); b--) {
-            const int t = N.id[b]; N.id[b] = N.id[b - 1]; N.id[b - 1] = t;
-            const double u = N.d2[b]; N.d2[b] = N.d2[b - 1]; N.d2[b - 1] = u;
-        }
+#define NPP_CSWAP(A, B)                                                                   \
+    if (key[B] < key[A]) {                                                                \
+        const int tk = key[A]; key[A] = key[B]; key[B] = tk;                              \
+        const int ti = N.id[A]; N.id[A] = N.id[B]; N.id[B] = ti;                          \
+        const double td = N.d2[A]; N.d2[A] = N.d2[B]; N.d2[B] = td;                       \
+    }
+    NPP_CSWAP(0, 1) NPP_CSWAP(2, 3) NPP_CSWAP(0, 2) NPP_CSWAP(1, 3) NPP_CSWAP(1, 2)
+#undef NPP_CSWAP
     if (N.n == 0) {
         // fallback: the first node in dict order with |x + 24 - px| < 24 and |y + 24 - py| < 24
         int best = -1, bk = 0x7fffffff;
