@@ -64,21 +64,31 @@ ALGO_BYTES_PER_REACH = 340
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def committed_traffic(kind="step"):
+def committed_traffic(kernel="step", workload="c0"):
     """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs) of this same
-    command; tools/profile_round.sh collects them and tools/summarize_profiles.py writes profiles/<round>_summary.json.
-    bench.py cannot run PMC passes on itself, so it reports the newest committed figure (or null)."""
+    command; tools/profile_round.sh collects them and tools/summarize_profiles.py writes profiles/<round>_summary.json (the
+    headline workload), <round>_render_summary.json (config 3: mines + player_frame) and <round>_c5_summary.json (config 5: doors,
+    full observation), each with a `by_kernel` table.  bench.py cannot run PMC passes on itself, so it reports the newest
+    committed figure for the kernel of the workload's own profile (or null) and names the file."""
     import glob
 
+    if workload == "zoo":
+        return None   # no committed PMC profile of the zoo kernels
+    suffix = {"mines": "_render_summary.json", "doors": "_c5_summary.json"}.get(workload, "_summary.json")
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
-        if ("render" in os.path.basename(f)) != (kind != "step"):
-            continue   # <round>_summary.json: the headline workload's step kernel; <round>_render_summary.json: the config-3 run
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix))):
+        name = os.path.basename(f)
+        if suffix == "_summary.json" and (name.endswith("_render_summary.json") or name.endswith("_c5_summary.json")):
+            continue
         try:
             j = json.load(open(f))
-            t = j.get("traffic" if kind == "step" else "render_traffic", {}).get("hbm_bytes_per_launch")
+            t = j.get("by_kernel", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+            if t is None and kernel == "step":
+                t = j.get("traffic", {}).get("hbm_bytes_per_launch")          # round 1-2 files
+            if t is None and kernel == "player_frame":
+                t = j.get("render_traffic", {}).get("hbm_bytes_per_launch")
             if t:
-                best = (float(t), os.path.basename(f))
+                best = (float(t), name)
         except Exception:
             pass
     return best
@@ -466,13 +476,13 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
                    "ticks_per_s": value * FRAME_SKIP, "preroll_steps": P, "player_frame": bool(player_frame or full_obs),
                    "gather_obs": bool(gather_rep is not None), "terminated_frac_last_step": done_frac},
         "launch_us": pl, "step_variant": step_variant, "stragglers": stragglers,
-        "roofline": hbm_roofline("npp_step_kernel", ALGO_BYTES_PER_ENV_STEP, n, pl, committed_traffic("step") or (None, None), STEP_NOTE),
+        "roofline": hbm_roofline("npp_step_kernel", ALGO_BYTES_PER_ENV_STEP, n, pl, committed_traffic("step", workload) or (None, None), STEP_NOTE),
     }
     if full_obs:
         blk["config"]["full_obs"] = True
     if render_us is not None:
         pr = percentiles(render_us)
-        blk["roofline_render"] = hbm_roofline("npp_render_kernel", ALGO_BYTES_PER_FRAME, n, pr, committed_traffic("render") or (None, None),
+        blk["roofline_render"] = hbm_roofline("npp_render_kernel", ALGO_BYTES_PER_FRAME, n, pr, committed_traffic("player_frame", workload) or (None, None),
                                               "7056 B written + ~0.2 KB read per env; parity of the raster is unpinned (no cairo/cv2 reference frame)")
         blk["roofline_render"]["launch_us"] = pr
     if stage_us:
@@ -480,11 +490,11 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
         blk["obs_kernels"] = dict(ok)
         blk["obs_kernels"]["note"] = ("HIP-event time of each observation kernel per step on the launch stream; npp_step includes "
                                       "spatial_context; reachability = table look-ups for the envs whose (cell, switch) key changed")
-        blk["roofline_render"] = hbm_roofline("npp_render_kernel", ALGO_BYTES_PER_FRAME, n, ok["player_frame"], (None, None),
+        blk["roofline_render"] = hbm_roofline("npp_render_kernel", ALGO_BYTES_PER_FRAME, n, ok["player_frame"], committed_traffic("player_frame", workload) or (None, None),
                                               "player_frame; raster parity unpinned (no cairo/cv2 reference frame)")
-        blk["roofline_global_view"] = hbm_roofline("npp_global_view_kernel", ALGO_BYTES_PER_GLOBAL_VIEW, n, ok["global_view"], (None, None),
+        blk["roofline_global_view"] = hbm_roofline("npp_global_view_kernel", ALGO_BYTES_PER_GLOBAL_VIEW, n, ok["global_view"], committed_traffic("global_view", workload) or (None, None),
                                                    "17 600 B written per env (the per-level view it patches is read through L2)")
-        blk["roofline_reach"] = hbm_roofline("npp_reach_kernel", ALGO_BYTES_PER_REACH, n, ok["reachability"], (None, None),
+        blk["roofline_reach"] = hbm_roofline("npp_reach_kernel", ALGO_BYTES_PER_REACH, n, ok["reachability"], committed_traffic("reachability", workload) or (None, None),
                                              "latency-bound table look-ups for the envs whose cache key changed")
     if gather_rep is not None:
         blk["with_obs_gather"] = gather_rep
