@@ -139,7 +139,9 @@ int npp_level_truncation_limit(const double *map, int64_t n, int32_t *limit, int
 
 /* NppEnvironment.step for all envs (base_environment.py:483-755): d_actions[N] in 0..5
  * (_actions_to_execute, :366-402), up to frame_skip ticks with early stop on win/death (:535-609),
- * truncation check (:613), observation (:627,680). */
+ * truncation check (:613), observation (:627,680).
+ * d_reward: the sparse terminal constants only (+20 win, -3 death, +10 exit switch) -- REWARD PARITY: NONE; the reference's
+ * reward is its PBRS calculator (reward_calculation/main_reward_calculator.py:225), which is out of scope. */
 int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_step_out *out);
 
 /* Several Gymnasium steps in ONE launch, for action sequences that do not depend on the observations in between: batched
@@ -170,7 +172,8 @@ int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y);
 
 /* switch_states observation (gym_environment/npp_environment.py:1782-1847): f32[n_envs][25] = up to 5 locked doors x
  * [switch x / 1056, switch y / 600, door x / 1056, door y / 600, collected]; the reference's door position falls back to the
- * switch position (its segment has no `p1`), reproduced.  No runnable reference for this one: parity by source reading. */
+ * switch position (its segment has no `p1`), reproduced.  Pinned by the reference's own two methods run on live entities
+ * (tests/golden/obs.npz, make_golden_obs.py). */
 int npp_switch_states(npp_handle h, float *d_out);
 
 /* reachability_features (f32[n_envs][38]) and mine_sdf_features (f32[n_envs][3]) of the current state of every env: what
@@ -179,11 +182,17 @@ int npp_switch_states(npp_handle h, float *d_out);
  * reference's cache rule -- the 38 floats are recomputed only when (ninja cell, exit_switch_activated) differs from the key of
  * the env's previous call, so call it once per observation (after npp_step / npp_reset), as the reference does.  The
  * per-level tables (sub-node graph, entity mask, flood fill, geometric Dijkstra from both goals, mine SDF) are built on the
- * host at the first call.  Either output may be NULL.  d_status (i32[n_envs], may be NULL): bit 0 set where the reference
- * would have left its level cache for the physics A* search (no node with a cached distance under the ninja), which is not
- * restated -- those rows carry the "unreachable" values.  NPP_ERR_UNSUPPORTED: a loaded level needs that search for every
- * query (several exit switches, or the exit door within 24 px of its switch), or an entity was moved with
- * npp_set_entity_pos.  Not meaningful between the steps of npp_step_many (the cache rule needs every observation). */
+ * host at the first call.  Levels whose exit door lies 12-24 px from its switch send every exit-door query of the reference through
+ * its cache-miss branch (physics A*, path_distance_calculator.py:744-845, 1218-1485): restated since round 3 -- per-level A* table
+ * on the host, the calculator's per-episode (start cell, goal cell) dictionary per env on the device (13 KB per env, allocated only
+ * when such a level is loaded; emptied when the env's episode counter moves, on npp_restore and on npp_assign_levels).
+ * Either output may be NULL.  d_status (i32[n_envs], may be NULL): bit 0 set where the reference would have taken that branch
+ * for a query the tables do not cover (no node with a cached distance under the ninja on a level without the A* table) -- those
+ * rows carry the "unreachable" values.  NPP_ERR_UNSUPPORTED: a loaded level has several exit switches (the reference then also
+ * leaves the level cache for the switch and runs a second search that is not restated), or an entity was moved with
+ * npp_set_entity_pos.  Not meaningful between the steps of npp_step_many (the cache rule needs every observation).
+ * mine_sdf_features: the VALUES are the reference's (MineSignedDistanceField); WHEN the reference's observation holds them (its
+ * reward calculator builds / clears that SDF) is not modelled -- parity of that life cycle is unpinned. */
 int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status);
 
 /* The whole gray frame of envs [env0, env0 + count): what NPlayHeadless.render() returns in grayscale mode
