@@ -375,36 +375,41 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
         parts = b.out.split_packed(gathered, world)
         ok = bool(torch.equal(parts["game_state"][rank].to(b.game_state.device), b.game_state))
         # the same with the gather taken off the critical path (nclone_amd.distributed.OverlappedObsGather): the collective of step t
-        # runs on a side stream while step t + 1 executes
-        from nclone_amd.distributed import OverlappedObsGather
+        # runs on a side stream while step t + 1 executes.  Guarded: RCCL has never run in the build environment, and a failure of
+        # this secondary figure must not take the line (and the serial figure) with it.
+        overlapped = None
+        try:
+            from nclone_amd.distributed import OverlappedObsGather
 
-        og = OverlappedObsGather(packed, world)
-        same = True
-        for k in range(P, P + 3):   # the bytes are those of the serial gather
-            b.step(acts[k], FRAME_SKIP, want_terminal=False)
-            gather()
-            torch.cuda.synchronize()
-            want = gathered.clone().cpu()
-            og.submit()
-            b.step(acts[k + 1], FRAME_SKIP, want_terminal=False)   # overwrites the block before the gather is collected
-            got = og.wait()
-            torch.cuda.synchronize()
-            same = same and bool(torch.equal(got.cpu(), want))
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(K):
-            b.step(acts[P + W + k], FRAME_SKIP, want_terminal=False)
-            og.submit()
-            if k:
-                og.wait()
-        og.wait()
-        barrier()
-        odt = max_over_ranks(time.perf_counter() - t0)
+            og = OverlappedObsGather(packed, world)
+            same = True
+            for k in range(P, P + 3):   # the bytes are those of the serial gather
+                b.step(acts[k], FRAME_SKIP, want_terminal=False)
+                gather()
+                torch.cuda.synchronize()
+                want = gathered.clone().cpu()
+                og.submit()
+                b.step(acts[k + 1], FRAME_SKIP, want_terminal=False)   # overwrites the block before the gather is collected
+                got = og.wait()
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(got.cpu(), want))
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(K):
+                b.step(acts[P + W + k], FRAME_SKIP, want_terminal=False)
+                og.submit()
+                if k:
+                    og.wait()
+            og.wait()
+            barrier()
+            odt = max_over_ranks(time.perf_counter() - t0)
+            overlapped = {"value": world * n * K / odt, "unit": "env-steps/s", "ms_per_step": odt * 1e3 / K, "bytes_equal_serial": same,
+                          "how": "snapshot of the packed block + all_gather on a side stream while the next step runs (double-buffered); "
+                                 "with gloo the host collective blocks inside wait()"}
+        except Exception as e:   # noqa: BLE001
+            overlapped = {"value": None, "error": repr(e)[:300]}
         gather_rep = {"value": world * n * K / gdt, "unit": "env-steps/s", "ms_per_step": gdt * 1e3 / K,
-                      "overlapped": {"value": world * n * K / odt, "unit": "env-steps/s", "ms_per_step": odt * 1e3 / K,
-                                     "bytes_equal_serial": same,
-                                     "how": "snapshot of the packed block + all_gather on a side stream while the next step runs "
-                                            "(double-buffered); with gloo the host collective blocks inside wait()"},
+                      "overlapped": overlapped,
                       "bytes_per_rank_per_step": int(packed.numel()), "collective": "all_gather_into_tensor (1 per step)",
                       "own_shard_roundtrip_ok": ok,
                       "fields": "game_state f32[41], entity_positions f32[6], reward f32, frames i16, action_mask i8[6], flags u8"}
@@ -562,8 +567,12 @@ def main():
             others["config4_shard"] = run_workload(ctx, "c3mixed", Ko, Wo, P)
             others["config5_full_obs"] = run_workload(ctx, "doors", Ko, Wo, P, full_obs=True)
         else:
-            # the north-star multi-GPU config: the mixed set on N GPUs, with and without the RCCL observation gather
-            others["config4"] = run_workload(ctx, "c3mixed", Ko, Wo, P, gather_obs=True)
+            # the north-star multi-GPU config: the mixed set on N GPUs, with and without the RCCL observation gather.  Guarded (on every
+            # rank alike): the headline must survive a failure of this block
+            try:
+                others["config4"] = run_workload(ctx, "c3mixed", Ko, Wo, P, gather_obs=True)
+            except Exception as e:   # noqa: BLE001
+                others["config4"] = {"value": None, "error": repr(e)[:400]}
 
     if rank == 0:
         levels = head.pop("_levels")

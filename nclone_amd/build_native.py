@@ -40,11 +40,12 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     flags += list(extra_flags)
     if verbose:
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
-    # plain step kernels (TU 0 single step, TU 2 npp_step_many): machine LICM off.  It hoists ~25 registers of fp64 literals (and as
-    # many scalar values) out of the tick loops and then spills to scratch memory to hold them; without it the G = 16 one-slot and
-    # uncapped builds need no scratch at all and run as fast (round 3: DESIGN.md 4.1, profiles/r03_kernel_resources.csv)
+    # step kernels: machine LICM off.  It hoists ~25 registers of fp64 literals (and as many scalar values) out of the tick loops and
+    # then spills to scratch memory to hold them; without it the G = 16 one-slot and uncapped builds need no scratch at all and run
+    # as fast, and the zoo kernels gain 4 % (round 3: DESIGN.md 4.1, profiles/r03_kernel_resources.csv).  The render kernels showed
+    # no difference and keep the default.
     NOLICM = ["-mllvm", "-disable-machine-licm"]
-    jobs = [("npp_kernels.hip", ["-DNPP_TU=%d" % k] + (NOLICM if k in (0, 2) else []), "npp_kernels_tu%d.o" % k) for k in range(4)]
+    jobs = [("npp_kernels.hip", ["-DNPP_TU=%d" % k] + NOLICM, "npp_kernels_tu%d.o" % k) for k in range(4)]
     jobs += [("npp_render.hip", [], "npp_render.o"), ("npp_capi.cpp", [], "npp_capi.o"), ("npp_level.cpp", [], "npp_level.o"),
              ("npp_reach_kernel.hip", [], "npp_reach_kernel.o"), ("npp_reach.cpp", [], "npp_reach.o"), ("npp_host.cpp", [], "npp_host.o")]
     procs = []

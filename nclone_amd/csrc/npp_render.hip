@@ -1260,6 +1260,9 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
         wave_sync();
     }
     const int nb = L.ctr[0];
+#ifdef NPP_GV_STATS
+    const unsigned long long t1b = __builtin_amdgcn_s_memtime();   // draw list + dirty boxes done; the patches follow
+#endif
     const uint8_t *canvas = a.tile_canvas + (size_t)lvl * 600 * 1056;
     // ---- the pixels inside the dirty boxes, composed ONE PER LANE into LDS patches (full wavefronts run the coverage sampler;
     //      the cell pass below then only sums bytes).  Boxes beyond the patch budget (many movers) are composed in the cell pass.
@@ -1404,7 +1407,8 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
                 uint32_t *dbg = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
                 dbg[0] = (uint32_t)(t1 - t0); dbg[1] = (uint32_t)(t2 - t1); dbg[2] = (uint32_t)(t3 - t2); dbg[3] = (uint32_t)(t4 - t3);
                 dbg[4] = (uint32_t)nd; dbg[5] = (uint32_t)nb; dbg[6] = (uint32_t)tot; dbg[7] = H.n_ent + H.n_mov;
-                for (int k = 8; k < 14; k++) dbg[k] = 0u;
+                dbg[8] = (uint32_t)(t1b - t1);
+                for (int k = 9; k < 14; k++) dbg[k] = 0u;
             }
 #endif
             return;
@@ -1447,7 +1451,8 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
         uint32_t *dbg = reinterpret_cast<uint32_t *>(out + (size_t)env * GV_CELLS);
         dbg[0] = (uint32_t)(t1 - t0); dbg[1] = (uint32_t)(t2 - t1); dbg[2] = (uint32_t)(t3 - t2); dbg[3] = (uint32_t)(t4 - t3);
         dbg[4] = (uint32_t)nd; dbg[5] = (uint32_t)nb; dbg[6] = (uint32_t)stat_nq; dbg[7] = H.n_ent + H.n_mov;
-        for (int k = 8; k < 14; k++) dbg[k] = 0u;
+        dbg[8] = (uint32_t)(t1b - t1);
+        for (int k = 9; k < 14; k++) dbg[k] = 0u;
     }
 #endif
     if (cost && lane == 0) cost[env] = (uint32_t)(__builtin_amdgcn_s_memtime() - cost_t0);

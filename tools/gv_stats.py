@@ -34,7 +34,7 @@ ev[1].record(b.stream)
 torch.cuda.synchronize()
 print("launch us", ev[0].elapsed_time(ev[1]) * 100)
 d = b.out.t["global_view"].reshape(n, -1)[:, :64].contiguous().cpu().numpy().view(np.uint32)
-names = ["copy", "list", "mark", "cells/export", "nd", "nb", "nq", "records", "K2 wave 0 clocks", "K2 nq", "K2 in-place flag", "K2 patch bytes"]
+names = ["copy", "list+patches", "mark", "cells/export", "nd", "nb", "nq", "records", "list only", "K2 nq", "K2 in-place flag", "K2 patch bytes"]
 for i, k in enumerate(names):
     col = d[:, i].astype(np.float64)
     print("%-8s mean %10.1f  p50 %8.0f  p95 %8.0f  max %8.0f" % (k, col.mean(), np.percentile(col, 50), np.percentile(col, 95), col.max()))
