@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
     auto append = [&](bool keep, const Draw &d) {
         const unsigned long long bal = __ballot(keep);
         const int pos = nd + __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep && pos < L.draw_cap) { L.draw[pos] = d; L.cbox[pos] = gv_cell_box(d); }
+        if (keep && pos < L.draw_cap) L.draw[pos] = d;   // (its cell box is computed later, and only if some row slice composes in place)
         nd += __popcll(bal);
     };
     if (H.n_door) {
@@ -1196,10 +1196,18 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
             Draw d = {}, di = {};
             const uint32_t k = d0 + lane;
             const bool kc = k < H.n_door && door_drawable(cc, k, d);
-            const bool ki = k < H.n_door && door_drawable(ci, k, di);
-            if (kc != ki || (kc && draw_differs(d, di))) {
-                if (kc) gv_push_box(L, d);
-                if (ki) gv_push_box(L, di);
+            // a door's stroke depends on its slot's state only: same state as after the reset = same drawable, no dirty box
+            bool same = true;
+            if (k < H.n_door) {
+                const int slot = (int)reinterpret_cast<const double *>(a.blob + H.off_doors)[5 * k + 4];
+                same = ent_state_ctx(cc, slot) == ent_state_ctx(ci, slot);
+            }
+            if (!same) {
+                const bool ki = door_drawable(ci, k, di);
+                if (kc != ki || (kc && draw_differs(d, di))) {
+                    if (kc) gv_push_box(L, d);
+                    if (ki) gv_push_box(L, di);
+                }
             }
             append(kc, d);
         }
@@ -1232,13 +1240,17 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
                     if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)zhead[4]; y = (float)zhead[5]; }
                     if (slot == H.obs_door && (ovr & ZOO_OVR_DOOR)) { x = (float)zhead[6]; y = (float)zhead[7]; }
                 }
-                if (live && !(x < wx0 || x > wx1 || y < wy0 || y > wy1))
-                    kc = rec_drawable(info, x, y, mover ? 1u : ent_state_of(a, env, slot), d);
-                if (!mover && !(x0 < wx0 || x0 > wx1 || y0 < wy0 || y0 > wy1))
-                    ki = rec_drawable(info, x0, y0, (init_words[slot >> 4] >> ((slot & 15) * 2)) & 3u, di);
-                if (kc != ki || (kc && draw_differs(d, di))) {
-                    if (kc) gv_push_box(L, d);
-                    if (ki) gv_push_box(L, di);
+                const uint32_t st_now = mover ? 1u : ent_state_of(a, env, slot);
+                const uint32_t st_init = (init_words[slot >> 4] >> ((slot & 15) * 2)) & 3u;
+                if (live && !(x < wx0 || x > wx1 || y < wy0 || y > wy1)) kc = rec_drawable(info, x, y, st_now, d);
+                // the usual record: a static entity in the state and at the place it has after a reset -> the drawable IS the
+                // init drawable, no dirty box, one evaluation instead of two (most of a level's mines, all its untouched gold)
+                if (mover || st_now != st_init || x != x0 || y != y0) {
+                    if (!mover && !(x0 < wx0 || x0 > wx1 || y0 < wy0 || y0 > wy1)) ki = rec_drawable(info, x0, y0, st_init, di);
+                    if (kc != ki || (kc && draw_differs(d, di))) {
+                        if (kc) gv_push_box(L, d);
+                        if (ki) gv_push_box(L, di);
+                    }
                 }
             }
             append(kc, d);
@@ -1248,11 +1260,9 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
     if (lane == 0) {   // the ninja, drawn last
         const Draw nj = {(float)px, (float)py, 10.f, 0.f, 0.f, 0.f, 0};
         L.draw[nd] = nj;
-        L.cbox[nd] = gv_cell_box(nj);
         gv_push_box(L, nj);
     }
     nd += 1;
-    for (int k = nd + lane; k < ((nd + 3) & ~3); k += 64) L.cbox[k] = make_uchar4(255, 0, 255, 0);   // pad the last group of four: empty
     wave_sync();
     if (L.ctr[0] > L.box_cap) {   // more dirty boxes than the list holds (a crowd of movers): everything is dirty, composed in the
         wave_sync();              // cell pass -- slow and exact
@@ -1284,6 +1294,13 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
         L.ctr[3] = used;
     }
     wave_sync();
+    // may a row slice have to compose pixels in place (a dirty box without a patch, or five boxes on one slice)?  Only then does the
+    // cell pass look at the drawables' cell boxes -- computed here, for the whole list, instead of at every append (round 3)
+    const bool may_inline = nb >= 5 || nb > npb || __any(lane < npb && L.prect[lane < npb ? lane : 0].z == 0);
+    if (may_inline) {
+        for (int k = lane; k < nd; k += 64) L.cbox[k] = gv_cell_box(L.draw[k]);
+        for (int k = nd + lane; k < ((nd + 3) & ~3); k += 64) L.cbox[k] = make_uchar4(255, 0, 255, 0);   // pad the last group of four: empty
+    }
     for (int b = 0; b < npb; b++) {
         const short4 pr = L.prect[b];
         if (pr.z == 0) continue;
@@ -1301,12 +1318,17 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
             bm[w] = __ballot(hit);
         }
         const int np = pr.z * pr.w, pbase = L.poff[b];
+        // row of pixel i = floor(i / width) without an integer division per pixel: (i + 0.5) / width lies at least 0.5 / width away
+        // from every integer, far more than the rounding error of the float product (i < 3072) for the widths drawables have; a
+        // wider rectangle keeps the division
+        const float rw = 1.f / (float)pr.z;
+        const bool narrow = pr.z <= 128;
         for (int i0 = lane; i0 < np; i0 += 128) {   // two pixels per lane and trip: their canvas loads overlap
             int xs[2], ys[2], cn[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int i = i0 + 64 * u < np ? i0 + 64 * u : i0;
-                const int yy = i / pr.z;
+                const int yy = narrow ? (int)(((float)i + 0.5f) * rw) : i / pr.z;
                 xs[u] = pr.x + (i - yy * pr.z); ys[u] = pr.y + yy;
                 cn[u] = canvas[(size_t)ys[u] * 1056 + xs[u]];
             }
@@ -1376,7 +1398,7 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
             }
             const int used = L.ctr[3];
             // may a row have to compose in place?  (a dirty box without a patch, or five boxes on one row slice)
-            const bool inl = nb >= 5 || nb > npb || __any(lane < npb && L.prect[lane < npb ? lane : 0].z == 0);
+            const bool inl = may_inline;
             if (lane == 0) *reinterpret_cast<int4 *>(x + XS_HDR) = make_int4(nd, nb, tot, used | (inl ? (int)0x80000000 : 0));
             {
                 uint2 *xb = reinterpret_cast<uint2 *>(x + XS_BOX);
