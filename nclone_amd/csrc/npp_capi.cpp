@@ -71,6 +71,21 @@ struct npp_handle_s {
     hipStream_t split_stream = nullptr;
     hipEvent_t split_ev[2] = {nullptr, nullptr};
     long tune_since = 0;             // launches since the last decision
+    // observation overlap (npp_set_obs_overlap): npp_step launches the `overlap_pct` % most expensive workgroups of the heavy-first
+    // order on split_stream and the rest on the caller's stream; while `forked`, every observation entry point launches its kernel
+    // once per part, each on the stream of the part it follows, so the observations of the cheap envs are produced while the
+    // expensive envs are still stepping.  join_streams() makes the caller's stream wait for the second one.
+    int overlap_pct = 0;
+    bool forked = false;
+    uint8_t *d_phase = nullptr;      // [n] which part stepped the env last
+    hipEvent_t ov_ev[3] = {nullptr, nullptr, nullptr};   // fork / order tables ready / join
+    // ... and the observation kernels do not wait for each other either: kind k (0 global_view, 1 player_frame, 2 reachability,
+    // 3 switch_states) of part p runs on side[k][p], forked off the stream that stepped the part (side_mask: which kinds; the others
+    // stay on the part's own stream)
+    unsigned side_mask = 0;
+    hipStream_t side[4][2] = {};
+    hipEvent_t side_ev[4][2] = {};   // fork, then reused for the join
+    bool side_busy[4][2] = {};
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
     unsigned char *d_rblob = nullptr;
@@ -110,6 +125,53 @@ int fail(npp_handle h, int code, const std::string &msg) {
 
 uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
+hipError_t second_stream_follows(npp_handle h);
+// observation overlap: the caller's stream waits for everything the other streams were given since the last split step
+hipError_t join_streams(npp_handle h) {
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 4; k++)
+        for (int p = 0; p < 2; p++)
+            if (h->side_busy[k][p]) {
+                h->side_busy[k][p] = false;
+                if (e == hipSuccess) e = hipEventRecord(h->side_ev[k][p], h->side[k][p]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->side_ev[k][p], 0);
+            }
+    if (!h->forked) return e;
+    h->forked = false;
+    if (e == hipSuccess) e = hipEventRecord(h->ov_ev[2], h->split_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ov_ev[2], 0);
+    return e;
+}
+// the stream observation kernel `kind` of part `part` is launched on: a side stream forked off the part's stream here, or that
+// stream itself.  `tables`: the caller's stream holds work the kernel needs (order tables) -- streams other than it wait for that.
+hipError_t obs_stream(npp_handle h, int kind, int part, bool tables, hipStream_t *out) {
+    hipStream_t src = part ? h->split_stream : h->stream;
+    hipError_t e = hipSuccess;
+    if (!(h->side_mask >> kind & 1) || !h->side[kind][part]) {
+        if (part && tables) e = second_stream_follows(h);
+        *out = src;
+        return e;
+    }
+    hipStream_t dst = h->side[kind][part];
+    if (!h->side_busy[kind][part]) {   // (a second call before the join just queues behind the first)
+        e = hipEventRecord(h->side_ev[kind][part], src);
+        if (e == hipSuccess) e = hipStreamWaitEvent(dst, h->side_ev[kind][part], 0);
+    }
+    if (e == hipSuccess && tables && (part || h->side_busy[kind][part])) {
+        e = hipEventRecord(h->ov_ev[1], h->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(dst, h->ov_ev[1], 0);
+    }
+    h->side_busy[kind][part] = true;
+    *out = dst;
+    return e;
+}
+// ... and the second stream waits for what the caller's stream holds now (order tables rebuilt ahead of an observation kernel)
+hipError_t second_stream_follows(npp_handle h) {
+    hipError_t e = hipEventRecord(h->ov_ev[1], h->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->split_stream, h->ov_ev[1], 0);
+    return e;
+}
+
 // Every entry point that launches, copies or allocates runs with the HANDLE's device current and puts the caller's device
 // back afterwards: a caller whose current device differs (another handle, another framework) must neither receive our
 // launch on its GPU nor find its own current device changed.
@@ -127,6 +189,10 @@ struct DeviceGuard {
 #define ON_DEVICE(h)                                                                                          \
     DeviceGuard _dg((h)->device);                                                                             \
     if (_dg.err != hipSuccess) return fail(h, NPP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dg.err))
+// every entry point but the observation kernels themselves first joins the two streams of a split step (see npp_set_obs_overlap)
+#define ON_DEVICE_JOINED(h)                                                                                   \
+    ON_DEVICE(h);                                                                                             \
+    HIP_TRY(h, join_streams(h))
 
 // Launch geometry (DESIGN.md "lanes per environment"): G lanes cooperate on one env.  The chip has 256 CUs x 4 SIMDs;
 // the path is a latency-bound fp64 dependency chain, so the grid is sized to put about two wavefronts on every SIMD
@@ -356,7 +422,7 @@ int apply_dynamic_truncation(npp_handle h, const uint8_t *mask) {
 int reset_impl(npp_handle h, const uint8_t *env_mask, int fresh, int fast = 0, int automatic = 0) {
     if (!h) return NPP_ERR_INVALID;
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reset: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     KernelArgs a = base_args(h);
     a.reset_fresh = fresh;
     a.fast_reset = fresh ? 0 : fast;
@@ -419,6 +485,14 @@ int npp_destroy(npp_handle h) {
     for (auto &e : h->tune_ev)
         if (e) hipEventDestroy(e);
     if (h->split_stream) { hipStreamDestroy(h->split_stream); hipEventDestroy(h->split_ev[0]); hipEventDestroy(h->split_ev[1]); }
+    for (auto &e : h->ov_ev)
+        if (e) hipEventDestroy(e);
+    for (int k = 0; k < 4; k++)
+        for (int p = 0; p < 2; p++) {
+            if (h->side[k][p]) hipStreamDestroy(h->side[k][p]);
+            if (h->side_ev[k][p]) hipEventDestroy(h->side_ev[k][p]);
+        }
+    hipFree(h->d_phase);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
     delete h;
@@ -431,13 +505,16 @@ int npp_set_stream(npp_handle h, void *hip_stream) {
         h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
         h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
     }
+    if (h->forked) {   // a split step is still in flight: its second stream joins the OLD stream
+        ON_DEVICE_JOINED(h);
+    }
     h->stream = (hipStream_t)hip_stream;
     return NPP_OK;
 }
 
 int npp_sync(npp_handle h) {
     if (!h) return NPP_ERR_INVALID;
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NPP_OK;
 }
@@ -445,7 +522,7 @@ int npp_sync(npp_handle h) {
 int npp_snapshot(npp_handle h) {
     if (!h) return NPP_ERR_INVALID;
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_snapshot: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     size_t N = (size_t)h->n;
     if (!h->s_f64) {
         HIP_TRY(h, hipMalloc((void **)&h->s_f64, sizeof(double) * NF64 * N));
@@ -485,7 +562,7 @@ int npp_restore(npp_handle h, const uint8_t *env_mask) {
     if (!h) return NPP_ERR_INVALID;
     if (!h->s_f64 || h->s_gen != h->assign_gen)
         return fail(h, NPP_ERR_STATE, "npp_restore: no snapshot for the current level assignment");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     KernelArgs a = base_args(h);
     if (env_mask) {
         HIP_TRY(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
@@ -529,7 +606,7 @@ int npp_num_levels(npp_handle h) { return h ? (int)h->levels.size() : 0; }
 
 int npp_load_levels(npp_handle h, const double *blob, const int64_t *offsets, int n_levels) {
     if (!h || !blob || !offsets || n_levels <= 0) return fail(h, NPP_ERR_INVALID, "npp_load_levels: bad arguments");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     std::vector<CompiledLevel> lv(n_levels);
     for (int i = 0; i < n_levels; i++) {
         std::string err;
@@ -669,7 +746,7 @@ int npp_assign_levels(npp_handle h, const int32_t *env_ids, const int32_t *level
     if (!h || !level_ids || n <= 0) return fail(h, NPP_ERR_INVALID, "npp_assign_levels: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_assign_levels: no levels loaded");
     if (!env_ids && n != h->n) return fail(h, NPP_ERR_INVALID, "npp_assign_levels: env_ids == NULL needs n == n_envs");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     std::vector<uint8_t> mask(h->n, 0);
     for (int i = 0; i < n; i++) {   // validate everything before touching the assignment: an error must leave host and device in step
         int e = env_ids ? env_ids[i] : i;
@@ -711,7 +788,7 @@ int npp_reset_ex(npp_handle h, const uint8_t *env_mask, int mode) {
 
 int npp_set_truncation_limit(npp_handle h, const int32_t *limits, int32_t all) {
     if (!h) return NPP_ERR_INVALID;
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     if (limits) h->trunc.assign(limits, limits + h->n);
     else h->trunc.assign(h->n, all);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -723,7 +800,7 @@ int npp_set_dynamic_truncation(npp_handle h, int enable) {
     if (!h) return NPP_ERR_INVALID;
     h->dyn_trunc = enable != 0;
     if (!h->dyn_trunc || h->levels.empty()) return NPP_OK;
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     return apply_dynamic_truncation(h, nullptr);
 }
 
@@ -795,6 +872,39 @@ int tune_next(npp_handle h, int *pair) {
 }
 }  // namespace
 
+int npp_set_obs_overlap(npp_handle h, int percent) {
+    if (!h || percent < 0 || percent >= 100) return fail(h, NPP_ERR_INVALID, "npp_set_obs_overlap: percent must be in [0, 100)");
+    ON_DEVICE_JOINED(h);
+    if (percent > 0 && !h->d_phase) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_phase, (size_t)h->n));
+        HIP_TRY(h, hipMemsetAsync(h->d_phase, 0, (size_t)h->n, h->stream));
+        if (!h->split_stream) {
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->split_ev[0], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->split_ev[1], hipEventDisableTiming));
+        }
+        for (auto &e : h->ov_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // player_frame beside the rest.  Measured (doors, full Dict, 40 %): no side stream 471 us per step, global_view 485,
+        // player_frame 436, both 555 -- HIP feeds a process through four hardware queues, so more streams than that share queues
+        // and serialise again
+        h->side_mask = 2;
+        if (const char *ev = std::getenv("NPP_OBS_SIDE")) h->side_mask = (unsigned)std::atoi(ev) & 15u;
+        for (int k = 0; k < 4; k++)
+            for (int p = 0; p < 2; p++) {
+                HIP_TRY(h, hipStreamCreateWithFlags(&h->side[k][p], hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->side_ev[k][p], hipEventDisableTiming));
+            }
+    }
+    h->overlap_pct = percent;
+    return NPP_OK;
+}
+
+int npp_join(npp_handle h) {
+    if (!h) return NPP_ERR_INVALID;
+    ON_DEVICE_JOINED(h);
+    return NPP_OK;
+}
+
 int npp_set_step_variant(npp_handle h, int variant) {
     if (!h || variant < -1 || variant > 2) return fail(h, NPP_ERR_INVALID, "npp_set_step_variant: variant must be -1 (autotune) or 0..2");
     h->variant_pin = variant;
@@ -812,7 +922,7 @@ int npp_get_step_variant(npp_handle h, int *variant, int *tuned) {
 int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_step_out *out) {
     if (!h || !d_actions || frame_skip <= 0) return fail(h, NPP_ERR_INVALID, "npp_step: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_step: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     KernelArgs a = base_args(h);
     a.inputs = d_actions;
     a.n_ticks = frame_skip;
@@ -863,6 +973,28 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
     }
     int pair = -1;
     a.variant = tune_next(h, &pair);
+    a.phase = h->d_phase;   // (NULL unless npp_set_obs_overlap is on) an unsplit launch is "part 0" everywhere
+    if (h->overlap_pct > 0 && h->d_phase && pair < 0 && (h->tuned || h->variant_pin >= 0 || h->geo_g != 16 || h->zoo_active)) {
+        // observation overlap: the workgroups at the head of the heavy-first order go to the second stream, the rest run here; the
+        // observation entry points called next launch one kernel per part.  Only with workgroups of whole reachability groups (16
+        // envs) and never on a launch the autotuner is timing.
+        const int epb = (64 / h->geo_g) * h->geo_wpb, blocks = (h->n + epb - 1) / epb;
+        const int heavy = (int)((long long)blocks * h->overlap_pct / 100);
+        if (epb % 16 == 0 && heavy > 0 && heavy < blocks) {
+            HIP_TRY(h, hipEventRecord(h->ov_ev[0], h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->split_stream, h->ov_ev[0], 0));
+            KernelArgs ah = a, al = a;
+            // the one-wavefront-per-SIMD build holds 310 registers: beside it neither the other part nor an observation kernel finds
+            // room on the SIMD, which is the point of the split (doors, full Dict: 502 us per step with it, 435-442 with build 0)
+            if (a.variant == 2) ah.variant = al.variant = 0;
+            ah.wg_first = 0; ah.wg_count = heavy; ah.phase_id = 1;
+            al.wg_first = heavy; al.wg_count = blocks - heavy; al.phase_id = 0;
+            h->forked = true;
+            HIP_TRY(h, launch_step(ah, h->split_stream));
+            HIP_TRY(h, launch_step(al, h->stream));
+            return NPP_OK;
+        }
+    }
     if (pair >= 0) hipEventRecord(h->tune_ev[2 * (size_t)pair], h->stream);
     const hipError_t le = launch_step(a, h->stream);
     if (pair >= 0) hipEventRecord(h->tune_ev[2 * (size_t)pair + 1], h->stream);
@@ -873,7 +1005,7 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
 int npp_step_many(npp_handle h, const uint8_t *d_actions, int n_steps, int frame_skip, const npp_step_out *out) {
     if (!h || !d_actions || frame_skip <= 0 || n_steps <= 0) return fail(h, NPP_ERR_INVALID, "npp_step_many: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_step_many: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     KernelArgs a = base_args(h);
     a.inputs = d_actions;
     a.n_ticks = frame_skip;
@@ -888,7 +1020,7 @@ int npp_step_many(npp_handle h, const uint8_t *d_actions, int n_steps, int frame
 int npp_tick(npp_handle h, const uint8_t *d_inputs, int n_ticks) {
     if (!h || !d_inputs || n_ticks <= 0) return fail(h, NPP_ERR_INVALID, "npp_tick: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_tick: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     KernelArgs a = base_args(h);
     a.inputs = d_inputs;
     a.n_ticks = n_ticks;
@@ -901,7 +1033,7 @@ int npp_tick(npp_handle h, const uint8_t *d_inputs, int n_ticks) {
 int npp_observe(npp_handle h, const npp_step_out *out) {
     if (!h || !out) return fail(h, NPP_ERR_INVALID, "npp_observe: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_observe: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     KernelArgs a = base_args(h);
     a.n_ticks = 0;
     a.mode = 0;
@@ -915,6 +1047,7 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_player_frame: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_player_frame: no levels loaded");
     ON_DEVICE(h);
+    bool tables = !h->d_canvas;   // (observation overlap) something the second stream has to wait for was put on the caller's stream
     if (int rc = ensure_canvas(h)) return rc;
     KernelArgs a = base_args(h);
     {   // heavy-first env order, rebuilt from the last launch's per-env clocks on every 8th launch
@@ -924,12 +1057,25 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
             HIP_TRY(h, hipMemsetAsync(h->d_pf_cost, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
             h->pf_launches = 0;
         }
-        if (h->pf_launches % 8 < 2) HIP_TRY(h, launch_cost_order(h->d_pf_cost, h->d_pf_order, h->n, 0, h->stream));
+        if (h->pf_launches % 8 < 2) {
+            HIP_TRY(h, launch_cost_order(h->d_pf_cost, h->d_pf_order, h->n, 0, h->stream));
+            tables = true;
+        }
         h->pf_launches++;
         a.wg_order = h->d_pf_order;
         a.wg_cost = h->d_pf_cost;
     }
-    HIP_TRY(h, launch_render(a, d_out, (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0, h->stream));
+    const int centered = (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0;
+    hipStream_t st = h->stream;
+    if (h->forked) {   // one kernel per part of the split step (npp_set_obs_overlap)
+        HIP_TRY(h, obs_stream(h, 1, 1, tables, &st));
+        a.phase = h->d_phase;
+        a.phase_id = 1;
+        HIP_TRY(h, launch_render(a, d_out, centered, st));
+        a.phase_id = 0;
+    }
+    if (h->overlap_pct > 0) HIP_TRY(h, obs_stream(h, 1, 0, tables, &st)); else st = h->stream;
+    HIP_TRY(h, launch_render(a, d_out, centered, st));
     return NPP_OK;
 }
 
@@ -938,7 +1084,7 @@ int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y) {
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_set_entity_pos: no levels loaded");
     const CompiledLevel &L = h->levels[h->env_level[env]];
     if (L.obs_switch < 0) return fail(h, NPP_ERR_STATE, "npp_set_entity_pos: the env's level has no exit switch / door");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     double *blk = h->d_zoo + (size_t)env * h->zoo_words;
     uint64_t w3 = 0;
@@ -965,7 +1111,16 @@ int npp_switch_states(npp_handle h, float *d_out) {
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_switch_states: no levels loaded");
     ON_DEVICE(h);
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_switch_states(a, d_out, h->stream));
+    hipStream_t st = h->stream;
+    if (h->forked) {
+        HIP_TRY(h, obs_stream(h, 3, 1, false, &st));
+        a.phase = h->d_phase;
+        a.phase_id = 1;
+        HIP_TRY(h, launch_switch_states(a, d_out, st));
+        a.phase_id = 0;
+    }
+    if (h->overlap_pct > 0) HIP_TRY(h, obs_stream(h, 3, 0, false, &st)); else st = h->stream;
+    HIP_TRY(h, launch_switch_states(a, d_out, st));
     return NPP_OK;
 }
 
@@ -974,16 +1129,26 @@ int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reachability: no levels loaded");
     if (h->n_ovr) return fail(h, NPP_ERR_UNSUPPORTED, "npp_reachability: exit switch / door repositioned with npp_set_entity_pos");
     ON_DEVICE(h);
+    const bool tables = !h->d_rhdr;
     if (int rc = ensure_reach(h)) return rc;
     KernelArgs a = base_args(h);
-    HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, h->stream));
+    hipStream_t st = h->stream;
+    if (h->forked) {   // (tables: ensure_reach has just built them on the caller's stream)
+        HIP_TRY(h, obs_stream(h, 2, 1, tables, &st));
+        a.phase = h->d_phase;
+        a.phase_id = 1;
+        HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, st));
+        a.phase_id = 0;
+    }
+    if (h->overlap_pct > 0) HIP_TRY(h, obs_stream(h, 2, 0, tables, &st)); else st = h->stream;
+    HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, st));
     return NPP_OK;
 }
 
 int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out) {
     if (!h || !d_out || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_render_frame: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_frame: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     if (int rc = ensure_canvas(h)) return rc;
     KernelArgs a = base_args(h);
     HIP_TRY(h, launch_full_frame(a, env0, count, d_out, h->stream));
@@ -994,19 +1159,34 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     if (!h || !d_out) return fail(h, NPP_ERR_INVALID, "npp_render_global_view: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_render_global_view: no levels loaded");
     ON_DEVICE(h);
+    const bool tables = !h->d_gv_h || !h->d_canvas;
     if (int rc = ensure_gv(h)) return rc;
     KernelArgs a = base_args(h);
     int max_records = 0;
     for (const LevelHdr &lh : h->hdrs) max_records = std::max(max_records, (int)(lh.n_door + lh.n_ent + lh.n_mov));
-    HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost,
-                                  (h->gv_launches++ % 4) < 2, h->stream));   // the order is rebuilt on launches 0, 1, 4, 5, 8, ... (costs exist from launch 1 on)
+    const int reorder = (h->gv_launches++ % 4) < 2;   // the order is rebuilt on launches 0, 1, 4, 5, 8, ... (costs exist from launch 1 on)
+    if (h->overlap_pct > 0) {   // one kernel per part of a split step, each on its own stream; the order table is rebuilt once, ahead of both
+        if (reorder) HIP_TRY(h, launch_cost_order(h->d_gv_cost, h->d_gv_order, h->n, 0, h->stream));
+        hipStream_t st = h->stream;
+        if (h->forked) {
+            HIP_TRY(h, obs_stream(h, 0, 1, reorder || tables, &st));
+            a.phase = h->d_phase;
+            a.phase_id = 1;
+            HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, 0, st));
+            a.phase_id = 0;
+        }
+        HIP_TRY(h, obs_stream(h, 0, 0, reorder || tables, &st));
+        HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, 0, st));
+        return NPP_OK;
+    }
+    HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, reorder, h->stream));
     return NPP_OK;
 }
 
 int npp_dump_state(npp_handle h, int env0, int count, double *f64_out, int32_t *i32_out) {
     if (!h || env0 < 0 || count <= 0 || env0 + count > h->n) return fail(h, NPP_ERR_INVALID, "npp_dump_state: bad range");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_dump_state: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     size_t N = (size_t)h->n;
     std::vector<double> f((size_t)NF64 * count);
@@ -1054,7 +1234,7 @@ int npp_dump_state(npp_handle h, int env0, int count, double *f64_out, int32_t *
 int npp_dump_entities(npp_handle h, int env, int32_t *out, int max, int *n_out) {
     if (!h || env < 0 || env >= h->n || !out || !n_out) return fail(h, NPP_ERR_INVALID, "npp_dump_entities: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_dump_entities: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const CompiledLevel &L = h->levels[h->env_level[env]];
     std::vector<uint32_t> w(h->n_words_max);
@@ -1073,7 +1253,7 @@ int npp_dump_entities(npp_handle h, int env, int32_t *out, int max, int *n_out) 
 int npp_entity_checksum(npp_handle h, int env0, int count, double *out) {
     if (!h || env0 < 0 || count <= 0 || env0 + count > h->n || !out) return fail(h, NPP_ERR_INVALID, "npp_entity_checksum: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_entity_checksum: no levels loaded");
-    ON_DEVICE(h);
+    ON_DEVICE_JOINED(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     size_t N = (size_t)h->n;
     std::vector<uint32_t> w((size_t)h->n_words_max * count);

@@ -116,8 +116,13 @@ struct KernelArgs {
     // workgroup steps, wg_cost[block] the shader clocks its last launch took (launch_cost_order rebuilds the order from the costs)
     const uint32_t *wg_order;
     uint32_t *wg_cost;
-    int wg_first, wg_count;   // cost-split launch (NPP_STEP_SPLIT): this launch covers entries [wg_first, wg_first + wg_count) of the
-                              // order; wg_count == 0 = the whole grid
+    int wg_first, wg_count;   // split launch: this launch covers entries [wg_first, wg_first + wg_count) of the order; wg_count == 0 =
+                              // the whole grid
+    // observation overlap (npp_set_obs_overlap): the step is launched in two parts -- the workgroups expected to run long on a second
+    // stream -- and every env remembers which part stepped it (`phase`, u8[n]); the observation kernels are then launched once per
+    // part, each instance on its part's stream, skipping the envs of the other part (phase_id < 0 or phase == NULL: no filter)
+    uint8_t *phase;
+    int phase_id;
     int variant;          // build variant of the G = 16 plain step kernels (npp_kernels.hip: VariantK); 0 everywhere else
     StepOut out;
 };

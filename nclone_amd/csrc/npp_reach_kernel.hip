@@ -26,6 +26,8 @@ __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const Reach
     __shared__ float sdfs[REACH_EPB * 3];
     __shared__ int fresh[REACH_EPB];      // 1: the env's row in `rows` was recomputed (write it back to the cache)
     const int env0 = blockIdx.x * REACH_EPB;
+    // observation overlap: the host splits a step only when its workgroups hold a multiple of 16 envs, so these 16 share a phase
+    if (a.phase && a.phase_id >= 0 && a.phase[env0] != (uint8_t)a.phase_id) return;
     const int n_here = min(REACH_EPB, a.n - env0);
     const int l = threadIdx.x;
     const int el = l >> 2, env = env0 + el;

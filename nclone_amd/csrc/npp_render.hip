@@ -691,6 +691,7 @@ __global__ __launch_bounds__(256, NPP_RENDER_OCC) void npp_render_kernel(KernelA
     if ((int)blockIdx.x >= a.n) return;
     // heavy-first: the envs whose frame took longest last time (many drawables in the window) are dispatched first
     const int env = a.wg_order ? (int)a.wg_order[blockIdx.x] : (int)blockIdx.x;
+    if (a.phase && a.phase_id >= 0 && a.phase[env] != (uint8_t)a.phase_id) return;   // stepped by the other part of a split launch
     const unsigned long long pf_t0 = a.wg_cost ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifdef NPP_RENDER_STAMPS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -1138,6 +1139,7 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
     if (slot >= a.n) return;
     // heavy envs first: `order` lists the envs by the clocks their wavefront took in an earlier launch (npp_gv_order_kernel)
     const int env = order ? (int)order[slot] : slot;
+    if (a.phase && a.phase_id >= 0 && a.phase[env] != (uint8_t)a.phase_id) return;   // stepped by the other part of a split launch
     const unsigned long long cost_t0 = __builtin_amdgcn_s_memtime();
 #ifdef NPP_GV_STATS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -1612,6 +1614,7 @@ __global__ __launch_bounds__(256) void npp_full_frame_kernel(KernelArgs a, int e
 __global__ __launch_bounds__(256) void npp_switch_states_kernel(KernelArgs a, float *out) {
     const int env = blockIdx.x * 256 + threadIdx.x;
     if (env >= a.n) return;
+    if (a.phase && a.phase_id >= 0 && a.phase[env] != (uint8_t)a.phase_id) return;
     const LevelHdr &H = a.hdr[a.env_level[env]];
     const double *ex = reinterpret_cast<const double *>(a.blob + H.off_ent_x);
     const double *ey = reinterpret_cast<const double *>(a.blob + H.off_ent_y);

@@ -239,6 +239,14 @@ class NppBatch:
         """Build variant of the step kernel: -1 = autotune on this handle's workload (default), 0..2 pin one (same bits either way)."""
         nat.check(self.h, self.lib.npp_set_step_variant(self.h, int(variant)))
 
+    def set_obs_overlap(self, percent=0):
+        """Observation overlap (include/npp_amd.h npp_set_obs_overlap): step the `percent` % most expensive workgroups on a second
+        stream so that the observation kernels of the other envs run beside them; call join() before consuming the outputs."""
+        nat.check(self.h, self.lib.npp_set_obs_overlap(self.h, int(percent)))
+
+    def join(self):
+        nat.check(self.h, self.lib.npp_join(self.h))
+
     def step_variant(self):
         """(variant npp_step launches now, True once the autotuner has decided or a variant is pinned)"""
         v, t = C.c_int(0), C.c_int(0)
@@ -376,6 +384,7 @@ class NppBatch:
         """{name: numpy array} of the enabled outputs through ONE async device-to-host copy of the output block into pinned
         memory on the handle's stream + one synchronisation.  The arrays are views of a pinned staging block; two blocks
         alternate, so they stay valid until the to_host() call after the next one."""
+        self.join()
         return self.out.to_host(self.stream, names)
 
     def sync(self):

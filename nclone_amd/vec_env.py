@@ -53,7 +53,7 @@ class NppVecEnvironment:
 
     def __init__(self, levels, num_envs, level_ids=None, frame_skip=4, device=0, enable_visual_observations=False,
                  truncation_limit="dynamic", output="torch", autoreset=True, enable_spatial_context=False,
-                 enable_switch_states=False, fast_reset=True, stream=None, enable_reachability=False):
+                 enable_switch_states=False, fast_reset=True, stream=None, enable_reachability=False, obs_overlap=0):
         assert output in ("torch", "numpy")
         self.num_envs = int(num_envs)
         self.frame_skip = int(frame_skip)
@@ -88,6 +88,8 @@ class NppVecEnvironment:
             self._b.set_dynamic_truncation(True)
         else:
             self._b.set_truncation_limit(truncation_limit)
+        if obs_overlap:   # speed knob (same bits): observation kernels of the cheap envs beside the step's expensive tail
+            self._b.set_obs_overlap(int(obs_overlap))
         self._rng = np.random.default_rng()
         with self._b._ctx():
             self._actions = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._b.device)
@@ -105,6 +107,7 @@ class NppVecEnvironment:
             b.render_global_view()
         if "reachability_features" in b.out.t:
             b.reachability()
+        b.join()   # (obs_overlap) the handle's stream waits for the kernels that went to the second stream
 
     def _obs(self, src):
         """src: {name: tensor-or-array} (device tensors, or the host views of ONE staged copy)."""

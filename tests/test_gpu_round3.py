@@ -336,3 +336,55 @@ def test_switch_states_match_the_reference_methods():
         bad = np.flatnonzero((h["switch_states"] != S[:, t + 1]).any(axis=1))
         assert len(bad) == 0, (t, [names[i] for i in bad])
     b.close()
+
+
+@pytest.mark.parametrize("percent", [12, 50])
+def test_observation_overlap_produces_the_serial_bits(percent):
+    """npp_set_obs_overlap: the expensive workgroups of the step on a second stream, one observation kernel per part.  Every
+    output of the block -- and the state behind it -- equals the unsplit run's after every step, across auto-resets, a masked
+    reset and a snapshot / restore (entry points that join the two streams themselves)."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import door_levels
+
+    levels, _tags = door_levels()
+    n = 2048
+    level_ids = (np.arange(n) // 32) % len(levels)
+    steps = 40
+    acts = torch.from_numpy(np.random.default_rng(5).integers(0, 6, size=(steps, n)).astype(np.uint8)).cuda()
+    runs = []
+    for pct in (0, percent):
+        b = NppBatch(n, autoreset=True, fast_reset=True, outputs=FULL)
+        b.load_levels(levels)
+        b.assign_levels(level_ids)
+        b.set_step_variant(1)          # a pinned build: the split starts with the first step (the autotuner never splits a timed launch)
+        b.set_obs_overlap(pct)
+        b.reset()
+        b.set_truncation_limit(25)
+        hist = []
+        for t in range(steps):
+            b.step(acts[t])
+            b.switch_states()
+            b.render_player_frame()
+            b.render_global_view()
+            b.reachability()
+            if t == 10:
+                b.snapshot()
+            if t == 20:
+                mask = np.zeros(n, np.uint8)
+                mask[::3] = 1
+                b.reset(mask)
+            if t == 30:
+                mask = np.zeros(n, np.uint8)
+                mask[1::2] = 1
+                b.restore(mask)
+            if t % 3 == 0 or t in (10, 20, 30):
+                hist.append({k: v.copy() for k, v in b.to_host().items()})
+        f, di = b.dump_state()
+        runs.append((hist, f, di))
+        del b
+    (h0, f0, d0), (h1, f1, d1) = runs
+    assert np.array_equal(f0, f1, equal_nan=True) and np.array_equal(d0, d1)
+    for a, c in zip(h0, h1):
+        assert a.keys() == c.keys()
+        for k in a:
+            assert np.array_equal(a[k], c[k], equal_nan=True), k
