@@ -363,7 +363,8 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
     overlap_rep = None
     if full_obs and args.obs_overlap:
         overlap_rep = []
-        for pct in [int(x) for x in args.obs_overlap.split(",") if x.strip()]:
+        for spec in [x.strip() for x in args.obs_overlap.split(",") if x.strip()]:
+            pct = [int(c) for c in spec.split("+")]   # "40" = one cut, "6+25+50" = three
             b.set_obs_overlap(pct)
             for k in range(P, P + W):
                 one(k)
@@ -377,7 +378,7 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
                 b.join()
             barrier()
             odt = max_over_ranks(time.perf_counter() - t0)
-            overlap_rep.append({"percent": pct, "value": world * n * K / odt, "unit": "env-steps/s", "ms_per_step": odt * 1e3 / K})
+            overlap_rep.append({"cuts_percent": pct, "value": world * n * K / odt, "unit": "env-steps/s", "ms_per_step": odt * 1e3 / K})
         b.set_obs_overlap(0)
 
     gather_rep = None
@@ -536,7 +537,7 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
         if best["value"] > value:
             blk["value"], blk["ms_per_step"] = best["value"], best["ms_per_step"]
             blk["config"]["ticks_per_s"] = best["value"] * FRAME_SKIP
-            blk["config"]["obs_overlap_percent"] = best["percent"]
+            blk["config"]["obs_overlap_cuts_percent"] = best["cuts_percent"]
     if gather_rep is not None:
         blk["with_obs_gather"] = gather_rep
     if async_rep is not None:

@@ -238,14 +238,16 @@ int npp_set_step_variant(npp_handle h, int variant);
 int npp_get_step_variant(npp_handle h, int *variant, int *tuned);
 
 /* Observation overlap (a speed knob for the full observation Dict; results are bit-identical with it on or off; no counterpart in the
- * reference).  With percent > 0, npp_step launches the `percent` % most expensive workgroups of its heavy-first order on a second
- * HIP stream of the handle and the rest on the handle's stream, and until the next join npp_render_player_frame,
- * npp_render_global_view, npp_reachability and npp_switch_states launch one kernel per part, each behind the part it reads: the
- * observations of the cheap environments are produced while the expensive ones are still stepping (a step launch ends with a tail
- * of a few long environments that leaves most of the chip idle).  npp_join makes the handle's stream wait for the second one --
- * call it before anything else consumes the step's or the observation kernels' outputs on the handle's stream; every other entry
- * point (npp_sync, npp_step, npp_reset, npp_snapshot ...) joins by itself.  percent = 0 (default) switches it off. */
+ * reference).  A step launch ends with a tail of a few long environments that leaves most of the chip idle.  With cuts c1 < c2 < ...
+ * (percentages, at most three) npp_step cuts its heavy-first workgroup order at those points and launches every piece ("part") as a
+ * kernel of its own, the most expensive first: the last piece (the cheap end) on the handle's stream, the others on HIP streams the
+ * handle owns.  Until the next join npp_render_player_frame, npp_render_global_view, npp_reachability and npp_switch_states launch
+ * one kernel per part, each behind the part it reads: the observations of the cheap environments are produced while the expensive
+ * ones are still stepping.  npp_join makes the handle's stream wait for the others -- call it before anything else consumes the
+ * step's or the observation kernels' outputs on the handle's stream; every other entry point (npp_sync, npp_step, npp_reset,
+ * npp_snapshot ...) joins by itself.  npp_set_obs_overlap(h, percent) = one cut; percent = 0 / n_cuts = 0 (default) switch it off. */
 int npp_set_obs_overlap(npp_handle h, int percent);
+int npp_set_obs_overlap_parts(npp_handle h, const int *cuts, int n_cuts);
 int npp_join(npp_handle h);
 
 /* Host-only: the per-level reachability tables of one level, stage by stage (CPU tests compare them with the reference's,

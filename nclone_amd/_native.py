@@ -29,7 +29,7 @@ EXPORTS = [
     "npp_compile_level_segments", "npp_compile_level_entities", "npp_set_step_variant", "npp_get_step_variant", "npp_num_envs", "npp_num_levels",
     "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many", "npp_render_frame", "npp_plan_zoo_block", "npp_reset_ex",
     "npp_reachability", "npp_reach_compile", "npp_reach_features_host", "npp_reach_compile_miss", "npp_reach_rollout_host", "npp_set_dynamic_truncation", "npp_level_truncation_limit",
-    "npp_set_obs_overlap", "npp_join",
+    "npp_set_obs_overlap", "npp_set_obs_overlap_parts", "npp_join",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
     L.npp_set_step_variant.argtypes = [H, C.c_int]
     L.npp_set_obs_overlap.argtypes = [H, C.c_int]
     L.npp_join.argtypes = [H]
+    L.npp_set_obs_overlap_parts.argtypes = [H, C.POINTER(C.c_int), C.c_int]
     L.npp_get_step_variant.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.npp_get_launch_geometry.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.npp_entity_checksum.argtypes = [H, C.c_int, C.c_int, C.POINTER(C.c_double)]

@@ -71,21 +71,25 @@ struct npp_handle_s {
     hipStream_t split_stream = nullptr;
     hipEvent_t split_ev[2] = {nullptr, nullptr};
     long tune_since = 0;             // launches since the last decision
-    // observation overlap (npp_set_obs_overlap): npp_step launches the `overlap_pct` % most expensive workgroups of the heavy-first
-    // order on split_stream and the rest on the caller's stream; while `forked`, every observation entry point launches its kernel
-    // once per part, each on the stream of the part it follows, so the observations of the cheap envs are produced while the
-    // expensive envs are still stepping.  join_streams() makes the caller's stream wait for the second one.
-    int overlap_pct = 0;
-    bool forked = false;
+    // observation overlap (npp_set_obs_overlap / npp_set_obs_overlap_parts): npp_step cuts its heavy-first workgroup order at
+    // cut_pct[] percent and launches every piece ("part") as a kernel of its own -- part 0, the cheap tail of the order, on the
+    // caller's stream, the others on part_stream[] -- and while live_parts > 1 every observation entry point launches one kernel per
+    // part on the stream of the part it reads, so the observations of the cheap envs are produced while the expensive envs are still
+    // stepping.  join_streams() makes the caller's stream wait for the others.
+    int n_cuts = 0;                  // 0 = off
+    int cut_pct[3] = {0, 0, 0};      // ascending, from the head (most expensive end) of the order
+    int live_parts = 1;              // parts of the last npp_step still to be joined (1 = it was not split)
     uint8_t *d_phase = nullptr;      // [n] which part stepped the env last
-    hipEvent_t ov_ev[3] = {nullptr, nullptr, nullptr};   // fork / order tables ready / join
-    // ... and the observation kernels do not wait for each other either: kind k (0 global_view, 1 player_frame, 2 reachability,
-    // 3 switch_states) of part p runs on side[k][p], forked off the stream that stepped the part (side_mask: which kinds; the others
-    // stay on the part's own stream)
+    hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] stays empty: part 0 runs on the caller's stream
+    hipEvent_t part_ev[4] = {nullptr, nullptr, nullptr, nullptr};        // join
+    hipEvent_t ov_ev[2] = {nullptr, nullptr};                           // fork / tables on the caller's stream ready
+    // ... and with two parts (four hardware queues feed a process) the observation kernels need not wait for each other either: the
+    // kinds (bit 0 global_view, 1 player_frame, 2 reachability, 3 switch_states) named in side_mask run on a side stream forked off
+    // the stream that stepped the part -- side[0][p] for global_view, side[1][p] shared by the other three
     unsigned side_mask = 0;
-    hipStream_t side[4][2] = {};
-    hipEvent_t side_ev[4][2] = {};   // fork, then reused for the join
-    bool side_busy[4][2] = {};
+    hipStream_t side[2][2] = {};
+    hipEvent_t side_ev[2][2] = {};   // fork, then reused for the join
+    bool side_busy[2][2] = {};
     // reachability observation (npp_reachability; built on first use): per-level tables + per-env cache
     ReachHdr *d_rhdr = nullptr;
     unsigned char *d_rblob = nullptr;
@@ -125,30 +129,35 @@ int fail(npp_handle h, int code, const std::string &msg) {
 
 uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
-hipError_t second_stream_follows(npp_handle h);
 // observation overlap: the caller's stream waits for everything the other streams were given since the last split step
 hipError_t join_streams(npp_handle h) {
     hipError_t e = hipSuccess;
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 2; k++)
         for (int p = 0; p < 2; p++)
             if (h->side_busy[k][p]) {
                 h->side_busy[k][p] = false;
                 if (e == hipSuccess) e = hipEventRecord(h->side_ev[k][p], h->side[k][p]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->side_ev[k][p], 0);
             }
-    if (!h->forked) return e;
-    h->forked = false;
-    if (e == hipSuccess) e = hipEventRecord(h->ov_ev[2], h->split_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ov_ev[2], 0);
+    for (int p = 1; p < h->live_parts; p++) {
+        if (e == hipSuccess) e = hipEventRecord(h->part_ev[p], h->part_stream[p]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->part_ev[p], 0);
+    }
+    h->live_parts = 1;
     return e;
 }
-// the stream observation kernel `kind` of part `part` is launched on: a side stream forked off the part's stream here, or that
-// stream itself.  `tables`: the caller's stream holds work the kernel needs (order tables) -- streams other than it wait for that.
+// the stream observation kernel `kind` of part `part` is launched on: the part's own stream, or (two parts only) a side stream
+// forked off it here.  `tables`: the caller's stream holds work the kernel needs (order tables) -- other streams wait for that.
 hipError_t obs_stream(npp_handle h, int kind, int part, bool tables, hipStream_t *out) {
-    hipStream_t src = part ? h->split_stream : h->stream;
+    hipStream_t src = part ? h->part_stream[part] : h->stream;
     hipError_t e = hipSuccess;
-    if (!(h->side_mask >> kind & 1) || !h->side[kind][part]) {
-        if (part && tables) e = second_stream_follows(h);
+    const bool aside = h->n_cuts == 1 && (h->side_mask >> kind & 1) != 0 && h->side[0][0] != nullptr;
+    kind = kind ? 1 : 0;
+    if (!aside) {
+        if (part && tables) {
+            e = hipEventRecord(h->ov_ev[1], h->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(src, h->ov_ev[1], 0);
+        }
         *out = src;
         return e;
     }
@@ -165,11 +174,22 @@ hipError_t obs_stream(npp_handle h, int kind, int part, bool tables, hipStream_t
     *out = dst;
     return e;
 }
-// ... and the second stream waits for what the caller's stream holds now (order tables rebuilt ahead of an observation kernel)
-hipError_t second_stream_follows(npp_handle h) {
-    hipError_t e = hipEventRecord(h->ov_ev[1], h->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->split_stream, h->ov_ev[1], 0);
-    return e;
+
+// One observation kernel: as it is on the caller's stream (overlap off), or once per part of the last split step, the most
+// expensive part first, each launch told which part's envs are its own.
+template <class F> int obs_launch(npp_handle h, KernelArgs a, int kind, bool tables, F &&launch) {
+    if (h->n_cuts == 0) {
+        HIP_TRY(h, launch(a, h->stream));
+        return NPP_OK;
+    }
+    hipStream_t st = h->stream;
+    a.phase = h->live_parts > 1 ? h->d_phase : nullptr;
+    for (int q = h->live_parts - 1; q >= 0; q--) {
+        HIP_TRY(h, obs_stream(h, kind, q, tables, &st));
+        a.phase_id = q;
+        HIP_TRY(h, launch(a, st));
+    }
+    return NPP_OK;
 }
 
 // Every entry point that launches, copies or allocates runs with the HANDLE's device current and puts the caller's device
@@ -487,7 +507,11 @@ int npp_destroy(npp_handle h) {
     if (h->split_stream) { hipStreamDestroy(h->split_stream); hipEventDestroy(h->split_ev[0]); hipEventDestroy(h->split_ev[1]); }
     for (auto &e : h->ov_ev)
         if (e) hipEventDestroy(e);
-    for (int k = 0; k < 4; k++)
+    for (int q = 1; q < 4; q++) {
+        if (h->part_stream[q]) hipStreamDestroy(h->part_stream[q]);
+        if (h->part_ev[q]) hipEventDestroy(h->part_ev[q]);
+    }
+    for (int k = 0; k < 2; k++)
         for (int p = 0; p < 2; p++) {
             if (h->side[k][p]) hipStreamDestroy(h->side[k][p]);
             if (h->side_ev[k][p]) hipEventDestroy(h->side_ev[k][p]);
@@ -505,7 +529,7 @@ int npp_set_stream(npp_handle h, void *hip_stream) {
         h->tune_state = 0; h->tune_count = 0; h->tuned = h->variant_pin >= 0;
         h->variant = h->variant_pin >= 0 ? h->variant_pin : 0;
     }
-    if (h->forked) {   // a split step is still in flight: its second stream joins the OLD stream
+    if (h->live_parts > 1 || h->n_cuts) {   // a split step may still be in flight: its other streams join the OLD stream
         ON_DEVICE_JOINED(h);
     }
     h->stream = (hipStream_t)hip_stream;
@@ -872,31 +896,41 @@ int tune_next(npp_handle h, int *pair) {
 }
 }  // namespace
 
-int npp_set_obs_overlap(npp_handle h, int percent) {
-    if (!h || percent < 0 || percent >= 100) return fail(h, NPP_ERR_INVALID, "npp_set_obs_overlap: percent must be in [0, 100)");
+int npp_set_obs_overlap_parts(npp_handle h, const int *cuts, int n_cuts) {
+    if (!h || n_cuts < 0 || n_cuts > 3 || (n_cuts && !cuts)) return fail(h, NPP_ERR_INVALID, "npp_set_obs_overlap_parts: at most three cuts");
+    for (int i = 0; i < n_cuts; i++)
+        if (cuts[i] <= (i ? cuts[i - 1] : 0) || cuts[i] >= 100)
+            return fail(h, NPP_ERR_INVALID, "npp_set_obs_overlap_parts: cuts must be ascending percentages in (0, 100)");
     ON_DEVICE_JOINED(h);
-    if (percent > 0 && !h->d_phase) {
+    if (n_cuts > 0 && !h->d_phase) {
         HIP_TRY(h, hipMalloc((void **)&h->d_phase, (size_t)h->n));
         HIP_TRY(h, hipMemsetAsync(h->d_phase, 0, (size_t)h->n, h->stream));
-        if (!h->split_stream) {
-            HIP_TRY(h, hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->split_ev[0], hipEventDisableTiming));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->split_ev[1], hipEventDisableTiming));
-        }
         for (auto &e : h->ov_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        // player_frame beside the rest.  Measured (doors, full Dict, 40 %): no side stream 471 us per step, global_view 485,
-        // player_frame 436, both 555 -- HIP feeds a process through four hardware queues, so more streams than that share queues
-        // and serialise again
+        // player_frame beside the rest.  Measured (doors, full Dict, two parts cut at 40 %): no side stream 471 us per step,
+        // global_view aside 485, player_frame aside 436, both 555 -- HIP feeds a process through four hardware queues, so more
+        // streams than that share queues and serialise again
         h->side_mask = 2;
         if (const char *ev = std::getenv("NPP_OBS_SIDE")) h->side_mask = (unsigned)std::atoi(ev) & 15u;
-        for (int k = 0; k < 4; k++)
-            for (int p = 0; p < 2; p++) {
-                HIP_TRY(h, hipStreamCreateWithFlags(&h->side[k][p], hipStreamNonBlocking));
-                HIP_TRY(h, hipEventCreateWithFlags(&h->side_ev[k][p], hipEventDisableTiming));
-            }
     }
-    h->overlap_pct = percent;
+    for (int q = 1; q <= n_cuts; q++)
+        if (!h->part_stream[q]) {
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->part_stream[q], hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->part_ev[q], hipEventDisableTiming));
+        }
+    if (n_cuts == 1 && h->side_mask && !h->side[0][0])
+        for (int k = 0; k < 2; k++)
+            for (int q = 0; q < 2; q++) {
+                HIP_TRY(h, hipStreamCreateWithFlags(&h->side[k][q], hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->side_ev[k][q], hipEventDisableTiming));
+            }
+    h->n_cuts = n_cuts;
+    for (int i = 0; i < n_cuts; i++) h->cut_pct[i] = cuts[i];
     return NPP_OK;
+}
+
+int npp_set_obs_overlap(npp_handle h, int percent) {
+    if (!h || percent < 0 || percent >= 100) return fail(h, NPP_ERR_INVALID, "npp_set_obs_overlap: percent must be in [0, 100)");
+    return npp_set_obs_overlap_parts(h, &percent, percent > 0 ? 1 : 0);
 }
 
 int npp_join(npp_handle h) {
@@ -974,24 +1008,32 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
     int pair = -1;
     a.variant = tune_next(h, &pair);
     a.phase = h->d_phase;   // (NULL unless npp_set_obs_overlap is on) an unsplit launch is "part 0" everywhere
-    if (h->overlap_pct > 0 && h->d_phase && pair < 0 && (h->tuned || h->variant_pin >= 0 || h->geo_g != 16 || h->zoo_active)) {
-        // observation overlap: the workgroups at the head of the heavy-first order go to the second stream, the rest run here; the
+    if (h->n_cuts > 0 && h->d_phase && pair < 0 && (h->tuned || h->variant_pin >= 0 || h->geo_g != 16 || h->zoo_active)) {
+        // observation overlap: the pieces of the heavy-first order as launches of their own, the most expensive first; the
         // observation entry points called next launch one kernel per part.  Only with workgroups of whole reachability groups (16
         // envs) and never on a launch the autotuner is timing.
         const int epb = (64 / h->geo_g) * h->geo_wpb, blocks = (h->n + epb - 1) / epb;
-        const int heavy = (int)((long long)blocks * h->overlap_pct / 100);
-        if (epb % 16 == 0 && heavy > 0 && heavy < blocks) {
-            HIP_TRY(h, hipEventRecord(h->ov_ev[0], h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->split_stream, h->ov_ev[0], 0));
-            KernelArgs ah = a, al = a;
-            // the one-wavefront-per-SIMD build holds 310 registers: beside it neither the other part nor an observation kernel finds
+        int edge[5] = {0, 0, 0, 0, 0};   // part q = n_cuts - i covers order entries [edge[i], edge[i + 1])
+        bool ok = epb % 16 == 0;
+        for (int i = 0; i < h->n_cuts; i++) {
+            edge[i + 1] = (int)((long long)blocks * h->cut_pct[i] / 100);
+            ok = ok && edge[i + 1] > edge[i];
+        }
+        edge[h->n_cuts + 1] = blocks;
+        ok = ok && edge[h->n_cuts + 1] > edge[h->n_cuts];
+        if (ok) {
+            // the one-wavefront-per-SIMD build holds 310 registers: beside it neither another part nor an observation kernel finds
             // room on the SIMD, which is the point of the split (doors, full Dict: 502 us per step with it, 435-442 with build 0)
-            if (a.variant == 2) ah.variant = al.variant = 0;
-            ah.wg_first = 0; ah.wg_count = heavy; ah.phase_id = 1;
-            al.wg_first = heavy; al.wg_count = blocks - heavy; al.phase_id = 0;
-            h->forked = true;
-            HIP_TRY(h, launch_step(ah, h->split_stream));
-            HIP_TRY(h, launch_step(al, h->stream));
+            if (a.variant == 2) a.variant = 0;
+            HIP_TRY(h, hipEventRecord(h->ov_ev[0], h->stream));
+            h->live_parts = h->n_cuts + 1;
+            for (int i = 0; i <= h->n_cuts; i++) {
+                const int q = h->n_cuts - i;
+                KernelArgs ap = a;
+                ap.wg_first = edge[i]; ap.wg_count = edge[i + 1] - edge[i]; ap.phase_id = q;
+                if (q) HIP_TRY(h, hipStreamWaitEvent(h->part_stream[q], h->ov_ev[0], 0));
+                HIP_TRY(h, launch_step(ap, q ? h->part_stream[q] : h->stream));
+            }
             return NPP_OK;
         }
     }
@@ -1066,17 +1108,7 @@ int npp_render_player_frame(npp_handle h, uint8_t *d_out) {
         a.wg_cost = h->d_pf_cost;
     }
     const int centered = (h->flags & NPP_FLAG_FRAME_CENTERED) ? 1 : 0;
-    hipStream_t st = h->stream;
-    if (h->forked) {   // one kernel per part of the split step (npp_set_obs_overlap)
-        HIP_TRY(h, obs_stream(h, 1, 1, tables, &st));
-        a.phase = h->d_phase;
-        a.phase_id = 1;
-        HIP_TRY(h, launch_render(a, d_out, centered, st));
-        a.phase_id = 0;
-    }
-    if (h->overlap_pct > 0) HIP_TRY(h, obs_stream(h, 1, 0, tables, &st)); else st = h->stream;
-    HIP_TRY(h, launch_render(a, d_out, centered, st));
-    return NPP_OK;
+    return obs_launch(h, a, 1, tables, [&](const KernelArgs &ka, hipStream_t st) { return launch_render(ka, d_out, centered, st); });
 }
 
 int npp_set_entity_pos(npp_handle h, int env, int kind, double x, double y) {
@@ -1111,17 +1143,7 @@ int npp_switch_states(npp_handle h, float *d_out) {
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_switch_states: no levels loaded");
     ON_DEVICE(h);
     KernelArgs a = base_args(h);
-    hipStream_t st = h->stream;
-    if (h->forked) {
-        HIP_TRY(h, obs_stream(h, 3, 1, false, &st));
-        a.phase = h->d_phase;
-        a.phase_id = 1;
-        HIP_TRY(h, launch_switch_states(a, d_out, st));
-        a.phase_id = 0;
-    }
-    if (h->overlap_pct > 0) HIP_TRY(h, obs_stream(h, 3, 0, false, &st)); else st = h->stream;
-    HIP_TRY(h, launch_switch_states(a, d_out, st));
-    return NPP_OK;
+    return obs_launch(h, a, 3, false, [&](const KernelArgs &ka, hipStream_t st) { return launch_switch_states(ka, d_out, st); });
 }
 
 int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status) {
@@ -1132,17 +1154,9 @@ int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t
     const bool tables = !h->d_rhdr;
     if (int rc = ensure_reach(h)) return rc;
     KernelArgs a = base_args(h);
-    hipStream_t st = h->stream;
-    if (h->forked) {   // (tables: ensure_reach has just built them on the caller's stream)
-        HIP_TRY(h, obs_stream(h, 2, 1, tables, &st));
-        a.phase = h->d_phase;
-        a.phase_id = 1;
-        HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, st));
-        a.phase_id = 0;
-    }
-    if (h->overlap_pct > 0) HIP_TRY(h, obs_stream(h, 2, 0, tables, &st)); else st = h->stream;
-    HIP_TRY(h, launch_reach(a, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, st));
-    return NPP_OK;
+    return obs_launch(h, a, 2, tables, [&](const KernelArgs &ka, hipStream_t st) {   // (tables: ensure_reach has just built them)
+        return launch_reach(ka, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, st);
+    });
 }
 
 int npp_render_frame(npp_handle h, int env0, int count, uint8_t *d_out) {
@@ -1165,19 +1179,11 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     int max_records = 0;
     for (const LevelHdr &lh : h->hdrs) max_records = std::max(max_records, (int)(lh.n_door + lh.n_ent + lh.n_mov));
     const int reorder = (h->gv_launches++ % 4) < 2;   // the order is rebuilt on launches 0, 1, 4, 5, 8, ... (costs exist from launch 1 on)
-    if (h->overlap_pct > 0) {   // one kernel per part of a split step, each on its own stream; the order table is rebuilt once, ahead of both
+    if (h->n_cuts > 0) {   // one kernel per part of a split step; the order table is rebuilt once, ahead of all of them
         if (reorder) HIP_TRY(h, launch_cost_order(h->d_gv_cost, h->d_gv_order, h->n, 0, h->stream));
-        hipStream_t st = h->stream;
-        if (h->forked) {
-            HIP_TRY(h, obs_stream(h, 0, 1, reorder || tables, &st));
-            a.phase = h->d_phase;
-            a.phase_id = 1;
-            HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, 0, st));
-            a.phase_id = 0;
-        }
-        HIP_TRY(h, obs_stream(h, 0, 0, reorder || tables, &st));
-        HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, 0, st));
-        return NPP_OK;
+        return obs_launch(h, a, 0, reorder || tables, [&](const KernelArgs &ka, hipStream_t st) {
+            return launch_global_view(ka, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, 0, st);
+        });
     }
     HIP_TRY(h, launch_global_view(a, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, reorder, h->stream));
     return NPP_OK;

@@ -878,8 +878,17 @@ __global__ __launch_bounds__(128) void npp_gv_static_v_kernel(const float *gv_h,
     gv_v[((size_t)lvl * GV_ROWS + r) * GV_COLS + col] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);   // cvRound + saturate
 }
 
-constexpr int GV_Q = 512, GV_WORDS = (GV_CELLS + 31) / 32;
-constexpr int GV_PBOX = 32, GV_PATCH = 3072;   // dirty boxes whose pixels are composed up front into LDS patches, patch bytes
+#ifndef NPP_GV_Q   // (the three LDS budgets are build options for occupancy A/B runs; running out of any of them stays exact)
+#define NPP_GV_Q 512
+#endif
+#ifndef NPP_GV_PATCH
+#define NPP_GV_PATCH 3072
+#endif
+#ifndef NPP_GV_BOX_MAX
+#define NPP_GV_BOX_MAX 192
+#endif
+constexpr int GV_Q = NPP_GV_Q, GV_WORDS = (GV_CELLS + 31) / 32;
+constexpr int GV_PBOX = 32, GV_PATCH = NPP_GV_PATCH;   // dirty boxes whose pixels are composed up front into LDS patches, patch bytes
 // The cell pass as a kernel of its own (round 2): npp_global_view_kernel's launch lasted as long as its HEAVIEST env (cell pass: 36 k
 // clocks at the median, 250-380 k at the maximum), so an env with at most GV_XQ dirty cells now EXPORTS what the cell pass needs
 // (boxes, patch rectangles, patches, the cell queue; the draw list only if some row may have to compose in place) to a per-env
@@ -894,7 +903,7 @@ constexpr int GV_PBOX = 32, GV_PATCH = 3072;   // dirty boxes whose pixels are c
 #ifndef NPP_GV_XWAVES
 #define NPP_GV_XWAVES 4
 #endif
-constexpr int GV_XQ = 1024, GV_ITEM_CELLS = 32, GV_BOX_MAX = 192, GV_XWAVES = NPP_GV_XWAVES;
+constexpr int GV_XQ = 1024, GV_ITEM_CELLS = 32, GV_BOX_MAX = NPP_GV_BOX_MAX, GV_XWAVES = NPP_GV_XWAVES;
 constexpr int XS_HDR = 0, XS_BOX = 16, XS_PRECT = XS_BOX + GV_BOX_MAX * 8, XS_POFF = XS_PRECT + GV_PBOX * 8, XS_QUEUE = XS_POFF + GV_PBOX * 2,
               XS_PATCH = XS_QUEUE + GV_XQ * 2, XS_DRAW = XS_PATCH + GV_PATCH, XS_CBOX = XS_DRAW + 224 * 28, XS_END = XS_CBOX + 224 * 4;
 static_assert(XS_DRAW % 16 == 0 && XS_PATCH % 4 == 0 && XS_END <= GV_XSTRIDE, "scratch block layout");

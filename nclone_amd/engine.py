@@ -239,10 +239,14 @@ class NppBatch:
         """Build variant of the step kernel: -1 = autotune on this handle's workload (default), 0..2 pin one (same bits either way)."""
         nat.check(self.h, self.lib.npp_set_step_variant(self.h, int(variant)))
 
-    def set_obs_overlap(self, percent=0):
-        """Observation overlap (include/npp_amd.h npp_set_obs_overlap): step the `percent` % most expensive workgroups on a second
-        stream so that the observation kernels of the other envs run beside them; call join() before consuming the outputs."""
-        nat.check(self.h, self.lib.npp_set_obs_overlap(self.h, int(percent)))
+    def set_obs_overlap(self, cuts=0):
+        """Observation overlap (include/npp_amd.h npp_set_obs_overlap_parts): cut the step's heavy-first workgroup order at `cuts`
+        (one percentage or up to three ascending ones) and run the pieces, and the observation kernels behind each, on streams of
+        their own; 0 / () switches it off.  Same bits; call join() (to_host() does) before consuming the outputs."""
+        cuts = [int(cuts)] if np.isscalar(cuts) else [int(c) for c in cuts]
+        cuts = [c for c in cuts if c > 0]
+        arr = (C.c_int * max(1, len(cuts)))(*cuts)
+        nat.check(self.h, self.lib.npp_set_obs_overlap_parts(self.h, arr, len(cuts)))
 
     def join(self):
         nat.check(self.h, self.lib.npp_join(self.h))

@@ -338,9 +338,10 @@ def test_switch_states_match_the_reference_methods():
     b.close()
 
 
-@pytest.mark.parametrize("percent", [12, 50])
-def test_observation_overlap_produces_the_serial_bits(percent):
-    """npp_set_obs_overlap: the expensive workgroups of the step on a second stream, one observation kernel per part.  Every
+@pytest.mark.parametrize("cuts", [12, 50, (6, 25, 50)])
+def test_observation_overlap_produces_the_serial_bits(cuts):
+    """npp_set_obs_overlap(_parts): the step's heavy-first order cut into two or four launches on streams of their own, one
+    observation kernel per part.  Every
     output of the block -- and the state behind it -- equals the unsplit run's after every step, across auto-resets, a masked
     reset and a snapshot / restore (entry points that join the two streams themselves)."""
     from nclone_amd.engine import NppBatch
@@ -352,7 +353,7 @@ def test_observation_overlap_produces_the_serial_bits(percent):
     steps = 40
     acts = torch.from_numpy(np.random.default_rng(5).integers(0, 6, size=(steps, n)).astype(np.uint8)).cuda()
     runs = []
-    for pct in (0, percent):
+    for pct in (0, cuts):
         b = NppBatch(n, autoreset=True, fast_reset=True, outputs=FULL)
         b.load_levels(levels)
         b.assign_levels(level_ids)

@@ -10,7 +10,7 @@ import torch
 from nclone_amd.engine import NppBatch
 from nclone_amd.levels import door_levels
 
-pct = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+pct = [int(c) for c in sys.argv[1].split('+')] if len(sys.argv) > 1 else [40]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 n = 8192
 levels, _ = door_levels()
