@@ -2068,6 +2068,8 @@ extern "C" int npp_debug_stamps(unsigned long long *out, int n_waves, int reset)
 }
 #endif
 
+#elif defined(NPP_STAMPS)
+// (diagnostic build: translation unit 0 holds everything, the stamp table is one device symbol)
 #elif NPP_TU == 1
 hipError_t launch_step_tu1(const KernelArgs &a, hipStream_t s) { return launch_step_zm<true, false>(a, s); }
 #elif NPP_TU == 2

@@ -23,10 +23,8 @@ def main():
     csrc = os.path.join(ROOT, "nclone_amd", "csrc")
     if not os.path.isfile(out) or "--build" in sys.argv:
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-DNPP_STAMPS", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-o", out] +
-                              [os.path.join(csrc, f) for f in ("npp_kernels.hip", "npp_render.hip", "npp_reach_kernel.hip", "npp_capi.cpp",
-                                                               "npp_level.cpp", "npp_reach.cpp")])
+        subprocess.check_call([sys.executable, "-m", "nclone_amd.build_native", "--out", out, "--", "-DNPP_STAMPS", "-Wno-unused-value",
+                               "-Wno-unused-result"], cwd=ROOT)
         if "--build" in sys.argv:
             return
     nat.LIB_PATH = out
@@ -45,7 +43,8 @@ def main():
     for g in [int(x) for x in ([v for v in sys.argv[1:] if not v.startswith("-")] or ["64", "16"])]:
         b = NppBatch(n, autoreset=True)
         b.load_levels(levels)
-        b.set_launch_geometry(g, 1)
+        b.set_launch_geometry(g, 4 if g <= 16 else 1)
+        b.set_step_variant(int(os.environ.get("NPP_STAMP_VARIANT", "1")))
         b.assign_levels((np.arange(n) // 64) % len(levels))
         for k in range(W):
             b.step(acts[k], 4, want_terminal=False)
