@@ -717,6 +717,17 @@ void pack_reach(const ReachBuilt &R, ReachHdr &hdr, std::vector<unsigned char> &
         hdr.off_sdf = append(R.sdf.data(), 4 * R.sdf.size());
         hdr.off_grad = append(R.grad.data(), 4 * R.grad.size());
     }
+    std::vector<ReachRec> rec(RNODES);
+    std::memset(rec.data(), 0, sizeof(ReachRec) * RNODES);
+    for (int id = 0; id < RNODES; id++) {
+        ReachRec &q = rec[id];
+        q.dist0 = R.dist[0][id]; q.dist1 = R.dist[1][id];
+        q.mh0x = R.mh[0][2 * id]; q.mh0y = R.mh[0][2 * id + 1];
+        q.hop0 = R.hop[0][id]; q.hop1 = R.hop[1][id];
+        q.in = R.in[id];
+        q.cgoal = hdr.off_cgoal ? R.cgoal[id] : 0xff;
+    }
+    hdr.off_rec = append(rec.data(), sizeof(ReachRec) * RNODES);
 }
 
 }  // namespace npp

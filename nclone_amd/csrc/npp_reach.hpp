@@ -62,9 +62,23 @@ struct ReachHdr {
     uint32_t off_cgoal;                // u8 [RNODES] index into cand[] for a temp start node, 0xff = none
     uint32_t off_astar;                // f64[n_cand][RNODES] raw A* cost start node -> cand[k]; NaN = pair not tabulated
     uint32_t sw_alias;                 // 1: switch and door share a 24-px cell, i.e. one key of the per-episode cache
-    uint32_t pad_;
+    uint32_t off_rec;                  // ReachRec[RNODES]: the per-node entries of the tables above side by side (what one feature vector
+                                       // reads of a node in ONE 48-byte record: the device kernel is a chain of dependent loads)
     uint64_t base;                     // byte offset of this level's tables in the blob of all levels
 };
+
+struct alignas(16) ReachRec {   // scalar members only: indexing a member array by the goal id would put the record into scratch memory
+    double dist0, dist1;   // off_dist
+    double mh0x, mh0y;     // off_mh, goal 0
+    int16_t hop0, hop1;    // off_hop
+    uint8_t in;            // off_in
+    uint8_t cgoal;         // off_cgoal (0xff without the table)
+    uint16_t pad0_;
+    uint64_t pad1_;
+    NPP_HD double dist(int g) const { return g ? dist1 : dist0; }
+    NPP_HD int hop(int g) const { return g ? hop1 : hop0; }
+};
+static_assert(sizeof(ReachRec) == 48, "three 16-byte loads per node");
 
 NPP_HD inline int reach_node_id(int x, int y) {   // tile-data pixel position (6 mod 12) -> node id, -1 outside the lattice
     if (x < 6 || y < 6) return -1;

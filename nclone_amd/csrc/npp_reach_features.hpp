@@ -39,7 +39,7 @@ struct ReachMiss {
 };
 
 // int(v // 24) (Python float floor division is exact; the quotient of the division below can be off by one ulp)
-NPP_HD inline int reach_cell24(double v) {
+NPP_HD inline __attribute__((always_inline)) int reach_cell24(double v) {
     int c = (int)floor(v / 24.0);
     if ((double)c * 24.0 > v) c--;
     if ((double)(c + 1) * 24.0 <= v) c++;
@@ -57,27 +57,66 @@ struct ReachTabs {
     NPP_HD const double *mh(int g) const { return reinterpret_cast<const double *>(blob + H->off_mh) + (long)g * RNODES * 2; }
     NPP_HD const float *sdf() const { return reinterpret_cast<const float *>(blob + H->off_sdf); }
     NPP_HD const float *grad() const { return reinterpret_cast<const float *>(blob + H->off_grad); }
+    NPP_HD const ReachRec *rec() const { return reinterpret_cast<const ReachRec *>(blob + H->off_rec); }
 };
 
 // position of a node in the iteration order of the reference's adjacency dict: tiles row-major, then (6,6) (18,6) (6,18) (18,18)
-NPP_HD inline int reach_order_key(int id) {
+NPP_HD inline __attribute__((always_inline)) int reach_order_key(int id) {
     const int i = id / RH, j = id % RH;
     return (((j >> 1) * 42 + (i >> 1)) << 2) | ((i & 1) | ((j & 1) << 1));
 }
 
-NPP_HD inline double reach_floor(double v) { return floor(v); }
+NPP_HD inline __attribute__((always_inline)) double reach_floor(double v) { return floor(v); }
 
 // find_ninja_node (pathfinding_utils.py:1331-1497) in two parts, because one feature vector calls it up to five times at the same
 // position: reach_near() gathers the nodes the ninja overlaps ONCE (with every table read of the gather issued up front instead
 // of one dependent load per lattice cell -- the device kernel is bound by exactly these chains), reach_pick() applies a call's rule.
+// a node's record in registers (plain scalars, read member by member: a whole-struct copy of the 48-byte record ends up in scratch)
+struct ReachNode {
+    double dist0, dist1, mh0x, mh0y;
+    int hop0, hop1, in, cgoal;
+    NPP_HD double dist(int g) const { return g ? dist1 : dist0; }
+    NPP_HD int hop(int g) const { return g ? hop1 : hop0; }
+};
+NPP_HD inline __attribute__((always_inline)) ReachNode reach_node_load(const ReachRec *recs, int id) {
+    const ReachRec &m = recs[id];
+    ReachNode q;
+    q.dist0 = m.dist0; q.dist1 = m.dist1; q.mh0x = m.mh0x; q.mh0y = m.mh0y;
+    q.hop0 = m.hop0; q.hop1 = m.hop1; q.in = m.in; q.cgoal = m.cgoal;
+    return q;
+}
+
 struct ReachNear {
     int n;            // overlapping nodes (0 .. 4), in the iteration order of the reference's adjacency dict
     int id[4];
     double d2[4];     // squared distance to the ninja
     int fallback;     // n == 0: the first node in dict order inside the 24-px box around the ninja, -1 = none
+    ReachNode rec[4]; // the table entries of id[k]
 };
 
-NPP_HD inline ReachNear reach_near(const ReachTabs &T, double px, double py) {
+// the table entries of node `id`: from the gathered records when it is one of them, else one record load
+NPP_HD inline __attribute__((always_inline)) ReachNode reach_rec(const ReachTabs &T, const ReachNear &N, int id) {
+    ReachNode q;   // selects on scalars, member by member (a conditional copy of a whole record goes through scratch memory)
+    q.dist0 = N.rec[0].dist0; q.dist1 = N.rec[0].dist1; q.mh0x = N.rec[0].mh0x; q.mh0y = N.rec[0].mh0y;
+    q.hop0 = N.rec[0].hop0; q.hop1 = N.rec[0].hop1; q.in = N.rec[0].in; q.cgoal = N.rec[0].cgoal;
+    bool found = N.n > 0 && N.id[0] == id;
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        const bool c = k < N.n && N.id[k] == id;
+        q.dist0 = c ? N.rec[k].dist0 : q.dist0; q.dist1 = c ? N.rec[k].dist1 : q.dist1;
+        q.mh0x = c ? N.rec[k].mh0x : q.mh0x; q.mh0y = c ? N.rec[k].mh0y : q.mh0y;
+        q.hop0 = c ? N.rec[k].hop0 : q.hop0; q.hop1 = c ? N.rec[k].hop1 : q.hop1;
+        q.in = c ? N.rec[k].in : q.in; q.cgoal = c ? N.rec[k].cgoal : q.cgoal;
+        found = found || c;
+    }
+    if (!found) {   // the fallback node of a ninja that overlaps none
+        const ReachNode m = reach_node_load(T.rec(), id);
+        q.dist0 = m.dist0; q.dist1 = m.dist1; q.mh0x = m.mh0x; q.mh0y = m.mh0y; q.hop0 = m.hop0; q.hop1 = m.hop1; q.in = m.in; q.cgoal = m.cgoal;
+    }
+    return q;
+}
+
+NPP_HD inline __attribute__((always_inline)) ReachNear reach_near(const ReachTabs &T, double px, double py) {
     const double nx = px - 24.0, ny = py - 24.0;
     const unsigned char *in = T.in();
     ReachNear N;
@@ -86,13 +125,13 @@ NPP_HD inline ReachNear reach_near(const ReachTabs &T, double px, double py) {
     const int i0 = (int)ceil((nx - 10.0 - 6.0) / 12.0), j0 = (int)ceil((ny - 10.0 - 6.0) / 12.0);
     const int i1 = (int)reach_floor((nx + 10.0 - 6.0) / 12.0), j1 = (int)reach_floor((ny + 10.0 - 6.0) / 12.0);
     int cid[4];
-    unsigned char present[4];
+    const ReachRec *recs = T.rec();
 #pragma unroll
     for (int k = 0; k < 4; k++) {   // (i0, j0) (i0, j0 + 1) (i0 + 1, j0) (i0 + 1, j0 + 1): the order of the reference's double loop
         const int i = i0 + (k >> 1), j = j0 + (k & 1);
         const bool ok = i <= i1 && j <= j1 && i >= 0 && i < RW && j >= 0 && j < RH;
         cid[k] = ok ? i * RH + j : -1;
-        present[k] = in[ok ? cid[k] : 0];   // unconditional, independent loads
+        N.rec[k] = reach_node_load(recs, ok ? cid[k] : 0);   // unconditional, independent loads: everything a feature vector reads of the node
     }
     // the four slots stay at fixed positions (compile-time indices: registers, not scratch memory): a slot that does not qualify
     // gets the largest key, a five-exchange sorting network puts the others first in dict order
@@ -101,18 +140,23 @@ NPP_HD inline ReachNear reach_near(const ReachTabs &T, double px, double py) {
     for (int k = 0; k < 4; k++) {
         const int idk = cid[k] < 0 ? 0 : cid[k];
         const double dx = reach_node_x(idk) - nx, dy = reach_node_y(idk) - ny, d2 = dx * dx + dy * dy;
-        const bool ok = cid[k] >= 0 && present[k] && d2 <= 100.0;
+        const bool ok = cid[k] >= 0 && N.rec[k].in && d2 <= 100.0;
         N.id[k] = idk; N.d2[k] = d2;
         key[k] = ok ? reach_order_key(idk) : 0x7fffffff;
         N.n += ok ? 1 : 0;
     }
-#define NPP_CSWAP(A, B)                                                                   \
-    if (key[B] < key[A]) {                                                                \
-        const int tk = key[A]; key[A] = key[B]; key[B] = tk;                              \
-        const int ti = N.id[A]; N.id[A] = N.id[B]; N.id[B] = ti;                          \
-        const double td = N.d2[A]; N.d2[A] = N.d2[B]; N.d2[B] = td;                       \
+#define NPP_CSEL(T, X, Y) { const T t_ = c_ ? (Y) : (X); (Y) = c_ ? (X) : (Y); (X) = t_; }
+#define NPP_CSWAP(A, B)                                                                                             \
+    {   /* selects on scalars, member by member: a conditional swap of whole records is compiled through scratch memory */ \
+        const bool c_ = key[B] < key[A];                                                                            \
+        NPP_CSEL(int, key[A], key[B]) NPP_CSEL(int, N.id[A], N.id[B]) NPP_CSEL(double, N.d2[A], N.d2[B])            \
+        NPP_CSEL(double, N.rec[A].dist0, N.rec[B].dist0) NPP_CSEL(double, N.rec[A].dist1, N.rec[B].dist1)          \
+        NPP_CSEL(double, N.rec[A].mh0x, N.rec[B].mh0x) NPP_CSEL(double, N.rec[A].mh0y, N.rec[B].mh0y)              \
+        NPP_CSEL(int, N.rec[A].hop0, N.rec[B].hop0) NPP_CSEL(int, N.rec[A].hop1, N.rec[B].hop1)                    \
+        NPP_CSEL(int, N.rec[A].in, N.rec[B].in) NPP_CSEL(int, N.rec[A].cgoal, N.rec[B].cgoal)                      \
     }
     NPP_CSWAP(0, 1) NPP_CSWAP(2, 3) NPP_CSWAP(0, 2) NPP_CSWAP(1, 3) NPP_CSWAP(1, 2)
+#undef NPP_CSEL
 #undef NPP_CSWAP
     if (N.n == 0) {
         // fallback: the first node in dict order with |x + 24 - px| < 24 and |y + 24 - py| < 24
@@ -136,24 +180,23 @@ NPP_HD inline ReachNear reach_near(const ReachTabs &T, double px, double py) {
 
 // goal_node < 0: no goal node given (closest overlapping node wins); otherwise the overlapping node with the smallest cached
 // distance to goal `g` wins (Euclidean to goal_node when not cached, or always when g < 0: the call carries no goal id).
-NPP_HD inline int reach_pick(const ReachTabs &T, const ReachNear &N, int goal_node, int g) {
+NPP_HD inline __attribute__((always_inline)) int reach_pick(const ReachTabs &T, const ReachNear &N, int goal_node, int g) {
     if (N.n == 0) return N.fallback;
     if (goal_node >= 0 && N.n > 1) {
         double dg[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) dg[k] = (g >= 0 && k < N.n) ? T.dist(g)[N.id[k]] : INFINITY;   // independent loads
+        for (int k = 0; k < 4; k++) dg[k] = (g >= 0 && k < N.n) ? N.rec[k].dist(g) : INFINITY;
         int best = -1;
         double bd = INFINITY;
         const double gx = reach_node_x(goal_node), gy = reach_node_y(goal_node);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k >= N.n) break;
+        for (int k = 0; k < 4; k++) {   // (no early exit: the slots keep compile-time indices, i.e. registers)
             double d = dg[k];
             if (d == INFINITY) {
                 const double ex = gx - reach_node_x(N.id[k]), ey = gy - reach_node_y(N.id[k]);
                 d = sqrt(ex * ex + ey * ey);   // ((gx - nx) ** 2 + (gy - ny) ** 2) ** 0.5 on integers
             }
-            if (d < bd) { bd = d; best = N.id[k]; }
+            if (k < N.n && d < bd) { bd = d; best = N.id[k]; }
         }
         if (best >= 0) return best;
     }
@@ -165,14 +208,14 @@ NPP_HD inline int reach_pick(const ReachTabs &T, const ReachNear &N, int goal_no
     return best;
 }
 
-NPP_HD inline int reach_find_ninja_node(const ReachTabs &T, double px, double py, int goal_node, int g) {
+NPP_HD inline __attribute__((always_inline)) int reach_find_ninja_node(const ReachTabs &T, double px, double py, int goal_node, int g) {
     return reach_pick(T, reach_near(T, px, py), goal_node, g);
 }
 
 // find_ninja_node with search_radius_override = R, or (R < 0) the "ANY closest node in the entire adjacency graph" loop that
 // follows the ladder in get_distance's miss branch: a linear scan in dict order.  goal_node >= 0 with more than one node in range:
 // the node closest to the goal node wins (Euclidean; first minimum in dict order), otherwise the one closest to the ninja.
-NPP_HD inline int reach_scan_node(const ReachTabs &T, double px, double py, double R, int goal_node) {
+NPP_HD inline __attribute__((always_inline)) int reach_scan_node(const ReachTabs &T, double px, double py, double R, int goal_node) {
     const double nx = px - 24.0, ny = py - 24.0;
     const unsigned char *in = T.in();
     int best = -1, bkey = 0, count = 0, gbest = -1, gkey = 0;
@@ -196,12 +239,12 @@ NPP_HD inline int reach_scan_node(const ReachTabs &T, double px, double py, doub
 // The miss branch for the exit door (path_distance_calculator.py:949-960 and 1218-1485): the raw cost of the calculator's
 // per-episode dictionary for the ninja's cell, computed and stored on the first query of the cell.  `peek`: look the entry up
 // without creating it (the switch's query, which only ever READS the shared key); returns NaN when absent.
-NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, const ReachNear &N, double px, double py, ReachMiss *M, bool peek, bool *miss) {
+NPP_HD inline __attribute__((always_inline)) double reach_exit_miss_raw(const ReachTabs &T, const ReachNear &N, double px, double py, ReachMiss *M, bool peek, bool *miss) {
     int cx = reach_cell24(px), cy = reach_cell24(py);
     cx = cx < 0 ? 0 : (cx > 43 ? 43 : cx);
     cy = cy < 0 ? 0 : (cy > 24 ? 24 : cy);
     const int cell = cx * 25 + cy;
-    if (M && M->stamp[cell] == M->epoch) return M->raw[cell];
+    if (M && M->stamp && M->stamp[cell] == M->epoch) return M->raw[cell];   // (stamp == NULL: no dictionary, like M == NULL)
     if (peek) return NAN;
     // temp start node: find_ninja_node, then the 48 / 150 px retries, then any closest node
     int t = reach_pick(T, N, -1, 0);
@@ -210,7 +253,7 @@ NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, const ReachNear &N,
     if (t < 0) t = reach_scan_node(T, px, py, -1.0, -1);
     double raw = INFINITY;
     if (t >= 0) {
-        const int k = T.cgoal()[t];
+        const int k = T.H->off_cgoal ? (int)reach_rec(T, N, t).cgoal : 0xff;
         if (k < (int)T.H->n_cand) {
             const int c = T.H->cand[k];
             // the final start node: get_distance still carries the INFERRED goal id ("switch") at this point, so among several overlapping
@@ -225,21 +268,22 @@ NPP_HD inline double reach_exit_miss_raw(const ReachTabs &T, const ReachNear &N,
             }
         } else *miss = true;
     }
-    if (M) { M->stamp[cell] = M->epoch; M->raw[cell] = raw; }
+    if (M && M->stamp) { M->stamp[cell] = M->epoch; M->raw[cell] = raw; }
     return raw;
 }
 
 // get_distance / get_geometric_distance on the level-cache path (they return the same number there).  g: 0 exit switch,
 // 1 exit door.  Returns +inf when unreachable; sets *miss when the reference would leave the level-cache path.
-NPP_HD inline double reach_level_distance(const ReachTabs &T, const ReachNear &N, double px, double py, int g, double entity_radius, bool *miss) {
+NPP_HD inline __attribute__((always_inline)) double reach_level_distance(const ReachTabs &T, const ReachNear &N, double px, double py, int g, double entity_radius, bool *miss) {
     const ReachHdr &H = *T.H;
     const double combined = 10.0 + entity_radius;
     const int gid = g == 1 ? H.exit_gid : 0;   // which goal's tables the reference reads (goal-id inference, see ReachHdr)
     const int sn = reach_pick(T, N, H.goal_node[2 + g], gid);   // goal node of get_distance: thresholds 16 / 22, then 32
     if (sn < 0) { *miss = true; return INFINITY; }
-    const double cached = T.dist(gid)[sn];
+    const ReachNode q = reach_rec(T, N, sn);
+    const double cached = q.dist(gid);
     if (cached == INFINITY) { *miss = true; return INFINITY; }
-    const int nh = T.hop(gid)[sn];
+    const int nh = q.hop(gid);
     if (nh >= 0) {
         const double pdx = reach_node_x(nh) - reach_node_x(sn), pdy = reach_node_y(nh) - reach_node_y(sn);
         // (path_dx ** 2 + path_dy ** 2) ** 0.5: 12 for a cardinal hop, 288 ** 0.5 for a diagonal one (== sqrt(288) under glibc)
@@ -257,7 +301,7 @@ NPP_HD inline double reach_level_distance(const ReachTabs &T, const ReachNear &N
 // get_distance (path_distance_calculator.py:847-1485).  g: 0 exit switch, 1 exit door.  Returns +inf when unreachable; sets *miss
 // when the reference would run a part of its miss branch that is not tabulated.  geometric = true: get_geometric_distance
 // (path_distance_calculator.py:1487-1975), which never looks at the per-episode dictionary.
-NPP_HD inline double reach_goal_distance(const ReachTabs &T, const ReachNear &N, double px, double py, int g, double entity_radius, ReachMiss *M,
+NPP_HD inline __attribute__((always_inline)) double reach_goal_distance(const ReachTabs &T, const ReachNear &N, double px, double py, int g, double entity_radius, ReachMiss *M,
                                          bool geometric, bool *miss) {
     const ReachHdr &H = *T.H;
     const int gx = H.goal_x[g], gy = H.goal_y[g];
@@ -278,11 +322,11 @@ NPP_HD inline double reach_goal_distance(const ReachTabs &T, const ReachNear &N,
     return reach_level_distance(T, N, px, py, g, entity_radius, miss);
 }
 
-NPP_HD inline float reach_clip01(double v) { return (float)(v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v)); }
+NPP_HD inline __attribute__((always_inline)) float reach_clip01(double v) { return (float)(v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v)); }
 
 // out[38]; sdf_out[3] = mine_sdf_features (value, gradient) at the ninja (npp_environment.py mine_sdf_features);
 // returns status: bit 0 = the reference would have run its physics A* fallback here (not restated)
-NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int total_mines, int deadly_mines, float *out, float *sdf_out,
+NPP_HD inline __attribute__((always_inline)) int reach_features(const ReachTabs &T, double px, double py, int total_mines, int deadly_mines, float *out, float *sdf_out,
                                  ReachMiss *M = nullptr) {
     const ReachHdr &H = *T.H;
     for (int k = 0; k < REACH_DIM; k++) out[k] = 0.f;
@@ -316,8 +360,11 @@ NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int t
     // out[12] = 0: the switch never reads as activated (see the header comment); current goal = "switch"
     int ninja_node = -1;
     if (sw_dir) ninja_node = reach_pick(T, N, -1, 0);
+    ReachNode nrec;
+    nrec.mh0x = nrec.mh0y = NAN; nrec.hop0 = -1;
     if (ninja_node >= 0) {
-        const int nh = T.hop(0)[ninja_node];
+        nrec = reach_rec(T, N, ninja_node);
+        const int nh = nrec.hop0;
         if (nh >= 0) {
             const double dx = (reach_node_x(nh) + 24) - px, dy = (reach_node_y(nh) + 24) - py, dist = sqrt(dx * dx + dy * dy);
             if (dist > 0.001) { out[13] = (float)(dx / dist); out[14] = (float)(dy / dist); }
@@ -356,7 +403,7 @@ NPP_HD inline int reach_features(const ReachTabs &T, double px, double py, int t
         }
     }
     if (ninja_node >= 0) {   // 22-24: 4-hop look-ahead direction and its alignment with the next hop
-        const double mx = T.mh(0)[ninja_node * 2], my = T.mh(0)[ninja_node * 2 + 1];
+        const double mx = nrec.mh0x, my = nrec.mh0y;
         if (mx == mx) {
             out[22] = (float)mx; out[23] = (float)my;
             if (out[13] != 0.f || out[14] != 0.f) {

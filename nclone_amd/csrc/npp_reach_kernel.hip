@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const Reach
                     deadly += __popc(~(b | (b >> 1)) & m);
                 }
             float f[REACH_DIM];
-            const int st = reach_features(T, px, py, H.n_mines, deadly, f, sd, M.stamp ? &M : nullptr);
+            const int st = reach_features(T, px, py, H.n_mines, deadly, f, sd, &M);   // (M.stamp == NULL: no dictionary; a selected pointer would put M into scratch)
 #pragma unroll
             for (int i = 0; i < REACH_DIM; i++) rows[el * ROW + i] = f[i];
             rows[el * ROW + REACH_DIM] = (float)st;
