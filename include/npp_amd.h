@@ -241,7 +241,7 @@ int npp_get_step_variant(npp_handle h, int *variant, int *tuned);
  * reference).  A step launch ends with a tail of a few long environments that leaves most of the chip idle.  With cuts c1 < c2 < ...
  * (percentages, at most three) npp_step cuts its heavy-first workgroup order at those points and launches every piece ("part") as a
  * kernel of its own, the most expensive first: the last piece (the cheap end) on the handle's stream, the others on HIP streams the
- * handle owns.  Until the next join npp_render_player_frame, npp_render_global_view, npp_reachability and npp_switch_states launch
+ * handle owns (chosen at set-up so that their kernels are seen to run beside the handle's stream: that call synchronises).  Until the next join npp_render_player_frame, npp_render_global_view, npp_reachability and npp_switch_states launch
  * one kernel per part, each behind the part it reads: the observations of the cheap environments are produced while the expensive
  * ones are still stepping.  npp_join makes the handle's stream wait for the others -- call it before anything else consumes the
  * step's or the observation kernels' outputs on the handle's stream; every other entry point (npp_sync, npp_step, npp_reset,

@@ -80,7 +80,14 @@ struct npp_handle_s {
     int cut_pct[3] = {0, 0, 0};      // ascending, from the head (most expensive end) of the order
     int live_parts = 1;              // parts of the last npp_step still to be joined (1 = it was not split)
     uint8_t *d_phase = nullptr;      // [n] which part stepped the env last
-    hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] stays empty: part 0 runs on the caller's stream
+    hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // part 0 = the cheap tail of the order, on the caller's stream
+    // the streams behind part_stream[1..] and side[][]: created by calibrate_streams(), which keeps only streams whose kernels were
+    // SEEN to run beside the caller's and beside each other (HIP spreads a process's streams over four hardware queues; two streams
+    // on one queue serialise, and which queue a new stream gets depends on every stream the process has created before)
+    std::vector<hipStream_t> owned;
+    hipStream_t owned_for = nullptr;   // the caller's stream they were chosen against
+    bool owned_valid = false;
+    hipEvent_t cal_ev[2] = {nullptr, nullptr};
     hipEvent_t part_ev[4] = {nullptr, nullptr, nullptr, nullptr};        // join
     hipEvent_t ov_ev[2] = {nullptr, nullptr};                           // fork / tables on the caller's stream ready
     // ... and with two parts (four hardware queues feed a process) the observation kernels need not wait for each other either: the
@@ -149,41 +156,101 @@ hipError_t join_streams(npp_handle h) {
 // the stream observation kernel `kind` of part `part` is launched on: the part's own stream, or (two parts only) a side stream
 // forked off it here.  `tables`: the caller's stream holds work the kernel needs (order tables) -- other streams wait for that.
 hipError_t obs_stream(npp_handle h, int kind, int part, bool tables, hipStream_t *out) {
-    hipStream_t src = part ? h->part_stream[part] : h->stream;
+    hipStream_t src = h->part_stream[part];
     hipError_t e = hipSuccess;
-    const bool aside = h->n_cuts == 1 && (h->side_mask >> kind & 1) != 0 && h->side[0][0] != nullptr;
+    const bool aside = h->n_cuts == 1 && (h->side_mask >> kind & 1) != 0 && h->side[kind ? 1 : 0][part] != nullptr;
     kind = kind ? 1 : 0;
-    if (!aside) {
-        if (part && tables) {
-            e = hipEventRecord(h->ov_ev[1], h->stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(src, h->ov_ev[1], 0);
-        }
-        *out = src;
-        return e;
-    }
-    hipStream_t dst = h->side[kind][part];
-    if (!h->side_busy[kind][part]) {   // (a second call before the join just queues behind the first)
+    hipStream_t dst = aside ? h->side[kind][part] : src;
+    if (aside && !h->side_busy[kind][part]) {   // (a second call before the join just queues behind the first)
         e = hipEventRecord(h->side_ev[kind][part], src);
         if (e == hipSuccess) e = hipStreamWaitEvent(dst, h->side_ev[kind][part], 0);
+        h->side_busy[kind][part] = true;
     }
-    if (e == hipSuccess && tables && (part || h->side_busy[kind][part])) {
+    if (e == hipSuccess && tables && dst != h->stream) {
         e = hipEventRecord(h->ov_ev[1], h->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(dst, h->ov_ev[1], 0);
     }
-    h->side_busy[kind][part] = true;
     *out = dst;
     return e;
+}
+
+// Do kernels on streams a and b run side by side?  Two idle wavefronts of `ticks` each, one per stream: b's ends about when a's
+// does, or a whole kernel later.  (Setup path: synchronises both streams.)
+bool streams_overlap(npp_handle h, hipStream_t a, hipStream_t b, long long ticks, float single_ms) {
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+    bool ok = hipEventRecord(h->cal_ev[0], a) == hipSuccess;
+    ok = ok && launch_spin(ticks, a) == hipSuccess && launch_spin(ticks, b) == hipSuccess;
+    ok = ok && hipEventRecord(h->cal_ev[1], b) == hipSuccess;
+    ok = ok && hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess;
+    float ms = 0.f;
+    if (!ok || hipEventElapsedTime(&ms, h->cal_ev[0], h->cal_ev[1]) != hipSuccess) return true;   // cannot tell: take the stream
+    return ms < 1.6f * single_ms;
+}
+
+// `need` streams of the handle's own that overlap with the caller's stream and with each other (see NppHandle::owned); when fewer
+// can be found among 12 candidates the rest are streams that do not -- slower, never wrong.
+int calibrate_streams(npp_handle h, int need) {
+    if (h->owned_valid && h->owned_for == h->stream && (int)h->owned.size() >= need) return NPP_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (hipStream_t st : h->owned) hipStreamDestroy(st);
+    h->owned.clear();
+    if (!h->cal_ev[0]) {
+        HIP_TRY(h, hipEventCreate(&h->cal_ev[0]));
+        HIP_TRY(h, hipEventCreate(&h->cal_ev[1]));
+    }
+    const long long ticks = 3000;   // 30 us of the 100 MHz wall clock
+    float single_ms = 0.03f;
+    {   // what one such kernel takes between two events on one stream (launch overhead included)
+        launch_spin(ticks, h->stream);   // warm: the code object
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipEventRecord(h->cal_ev[0], h->stream));
+        HIP_TRY(h, launch_spin(ticks, h->stream));
+        HIP_TRY(h, hipEventRecord(h->cal_ev[1], h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->cal_ev[0], h->cal_ev[1]) == hipSuccess && ms > 0.f) single_ms = ms;
+    }
+    std::vector<hipStream_t> rejected;
+    for (int c = 0; c < 12 && (int)h->owned.size() < need; c++) {
+        hipStream_t st = nullptr;
+        HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        bool ok = streams_overlap(h, h->stream, st, ticks, single_ms);
+        for (size_t i = 0; ok && i < h->owned.size(); i++) ok = streams_overlap(h, h->owned[i], st, ticks, single_ms);
+        (ok ? h->owned : rejected).push_back(st);   // a rejected stream stays alive until the search ends: it keeps its queue busy
+    }
+    while ((int)h->owned.size() < need && !rejected.empty()) { h->owned.push_back(rejected.back()); rejected.pop_back(); }
+    for (hipStream_t st : rejected) hipStreamDestroy(st);
+    while ((int)h->owned.size() < need) {
+        hipStream_t st = nullptr;
+        HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->owned.push_back(st);
+    }
+    h->owned_for = h->stream;
+    h->owned_valid = true;
+    // hand them out: the parts first, then (two parts only) the side streams in use
+    int k = 0;
+    h->part_stream[0] = h->stream;
+    for (int q = 1; q <= h->n_cuts; q++) h->part_stream[q] = h->owned[k++];
+    for (int i = 0; i < 2; i++)
+        for (int q = 0; q < 2; q++) {
+            const bool used = h->n_cuts == 1 && (i ? (h->side_mask & 14u) : (h->side_mask & 1u));
+            h->side[i][q] = used ? h->owned[k++] : nullptr;
+        }
+    return NPP_OK;
+}
+int streams_needed(npp_handle h) {
+    return h->n_cuts + (h->n_cuts == 1 ? 2 * (((h->side_mask & 14u) ? 1 : 0) + ((h->side_mask & 1u) ? 1 : 0)) : 0);
 }
 
 // One observation kernel: as it is on the caller's stream (overlap off), or once per part of the last split step, the most
 // expensive part first, each launch told which part's envs are its own.
 template <class F> int obs_launch(npp_handle h, KernelArgs a, int kind, bool tables, F &&launch) {
-    if (h->n_cuts == 0) {
+    if (h->live_parts <= 1) {   // overlap off, or the last step was not split
         HIP_TRY(h, launch(a, h->stream));
         return NPP_OK;
     }
     hipStream_t st = h->stream;
-    a.phase = h->live_parts > 1 ? h->d_phase : nullptr;
+    a.phase = h->d_phase;
     for (int q = h->live_parts - 1; q >= 0; q--) {
         HIP_TRY(h, obs_stream(h, kind, q, tables, &st));
         a.phase_id = q;
@@ -507,15 +574,14 @@ int npp_destroy(npp_handle h) {
     if (h->split_stream) { hipStreamDestroy(h->split_stream); hipEventDestroy(h->split_ev[0]); hipEventDestroy(h->split_ev[1]); }
     for (auto &e : h->ov_ev)
         if (e) hipEventDestroy(e);
-    for (int q = 1; q < 4; q++) {
-        if (h->part_stream[q]) hipStreamDestroy(h->part_stream[q]);
+    for (hipStream_t st : h->owned) hipStreamDestroy(st);
+    for (auto &e : h->cal_ev)
+        if (e) hipEventDestroy(e);
+    for (int q = 0; q < 4; q++)
         if (h->part_ev[q]) hipEventDestroy(h->part_ev[q]);
-    }
     for (int k = 0; k < 2; k++)
-        for (int p = 0; p < 2; p++) {
-            if (h->side[k][p]) hipStreamDestroy(h->side[k][p]);
+        for (int p = 0; p < 2; p++)
             if (h->side_ev[k][p]) hipEventDestroy(h->side_ev[k][p]);
-        }
     hipFree(h->d_phase);
     free_reach(h);
     hipFree(h->s_f64); hipFree(h->s_u32); hipFree(h->s_ent); hipFree(h->s_sc); hipFree(h->d_zoo); hipFree(h->s_zoo);
@@ -533,6 +599,7 @@ int npp_set_stream(npp_handle h, void *hip_stream) {
         ON_DEVICE_JOINED(h);
     }
     h->stream = (hipStream_t)hip_stream;
+    h->part_stream[0] = h->stream;   // (observation overlap) the other streams are chosen again at the next split step
     return NPP_OK;
 }
 
@@ -912,19 +979,16 @@ int npp_set_obs_overlap_parts(npp_handle h, const int *cuts, int n_cuts) {
         h->side_mask = 2;
         if (const char *ev = std::getenv("NPP_OBS_SIDE")) h->side_mask = (unsigned)std::atoi(ev) & 15u;
     }
-    for (int q = 1; q <= n_cuts; q++)
-        if (!h->part_stream[q]) {
-            HIP_TRY(h, hipStreamCreateWithFlags(&h->part_stream[q], hipStreamNonBlocking));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->part_ev[q], hipEventDisableTiming));
-        }
-    if (n_cuts == 1 && h->side_mask && !h->side[0][0])
-        for (int k = 0; k < 2; k++)
-            for (int q = 0; q < 2; q++) {
-                HIP_TRY(h, hipStreamCreateWithFlags(&h->side[k][q], hipStreamNonBlocking));
-                HIP_TRY(h, hipEventCreateWithFlags(&h->side_ev[k][q], hipEventDisableTiming));
-            }
+    for (int q = 0; q < 4; q++)
+        if (!h->part_ev[q]) HIP_TRY(h, hipEventCreateWithFlags(&h->part_ev[q], hipEventDisableTiming));
+    for (int k = 0; k < 2; k++)
+        for (int q = 0; q < 2; q++)
+            if (!h->side_ev[k][q]) HIP_TRY(h, hipEventCreateWithFlags(&h->side_ev[k][q], hipEventDisableTiming));
+    if (n_cuts != h->n_cuts) h->owned_valid = false;
     h->n_cuts = n_cuts;
     for (int i = 0; i < n_cuts; i++) h->cut_pct[i] = cuts[i];
+    if (n_cuts > 0)
+        if (int rc = calibrate_streams(h, streams_needed(h))) return rc;
     return NPP_OK;
 }
 
@@ -1025,6 +1089,8 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
             // the one-wavefront-per-SIMD build holds 310 registers: beside it neither another part nor an observation kernel finds
             // room on the SIMD, which is the point of the split (doors, full Dict: 502 us per step with it, 435-442 with build 0)
             if (a.variant == 2) a.variant = 0;
+            if (!h->owned_valid || h->owned_for != h->stream)   // (first split step after npp_set_stream: one-off, synchronises)
+                if (int rc = calibrate_streams(h, streams_needed(h))) return rc;
             HIP_TRY(h, hipEventRecord(h->ov_ev[0], h->stream));
             h->live_parts = h->n_cuts + 1;
             for (int i = 0; i <= h->n_cuts; i++) {
@@ -1032,7 +1098,7 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
                 KernelArgs ap = a;
                 ap.wg_first = edge[i]; ap.wg_count = edge[i + 1] - edge[i]; ap.phase_id = q;
                 if (q) HIP_TRY(h, hipStreamWaitEvent(h->part_stream[q], h->ov_ev[0], 0));
-                HIP_TRY(h, launch_step(ap, q ? h->part_stream[q] : h->stream));
+                HIP_TRY(h, launch_step(ap, h->part_stream[q]));
             }
             return NPP_OK;
         }
@@ -1179,7 +1245,7 @@ int npp_render_global_view(npp_handle h, uint8_t *d_out) {
     int max_records = 0;
     for (const LevelHdr &lh : h->hdrs) max_records = std::max(max_records, (int)(lh.n_door + lh.n_ent + lh.n_mov));
     const int reorder = (h->gv_launches++ % 4) < 2;   // the order is rebuilt on launches 0, 1, 4, 5, 8, ... (costs exist from launch 1 on)
-    if (h->n_cuts > 0) {   // one kernel per part of a split step; the order table is rebuilt once, ahead of all of them
+    if (h->live_parts > 1) {   // one kernel per part of a split step; the order table is rebuilt once, ahead of all of them
         if (reorder) HIP_TRY(h, launch_cost_order(h->d_gv_cost, h->d_gv_order, h->n, 0, h->stream));
         return obs_launch(h, a, 0, reorder || tables, [&](const KernelArgs &ka, hipStream_t st) {
             return launch_global_view(ka, max_records, h->d_gv_p, h->d_gv_h, h->d_gv_v, d_out, h->d_gv_x, h->d_gv_order, h->d_gv_cost, 0, st);

@@ -185,6 +185,7 @@ hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned 
 hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, const float *src_cache, uint32_t *key, float *cache,
                                 const ReachMissDev &md, hipStream_t s);
 // order <- the indices 0 .. n - 1 sorted by cost, heaviest first (128 logarithmic bins; any costs give a permutation)
+hipError_t launch_spin(long long ticks, hipStream_t s);   // a bounded idle wavefront (stream calibration)
 hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, int fold, hipStream_t s);
 hipError_t launch_tile_tables(hipStream_t s);   // per-device tile gray tables of the player_frame kernel
 hipError_t launch_tile_canvas(const LevelHdr *d_hdr, const unsigned char *d_blob, uint8_t *d_canvas, int n_levels, hipStream_t s);

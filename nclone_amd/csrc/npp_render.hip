@@ -1673,6 +1673,18 @@ hipError_t launch_global_view(const KernelArgs &a, int max_records, const uint8_
     return hipGetLastError();
 }
 
+// One wavefront that does nothing for `ticks` of the 100 MHz wall clock (bounded): the observation overlap's stream calibration launches
+// two of them on two streams and looks at whether they ran side by side (npp_capi.cpp: streams_overlap).
+__global__ __launch_bounds__(64) void npp_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    ticks = ticks > 100000 ? 100000 : ticks;   // at most 1 ms, whatever the caller asks for
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_spin(long long ticks, hipStream_t s) {
+    hipLaunchKernelGGL(npp_spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+    return hipGetLastError();
+}
+
 hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, int fold, hipStream_t s) {
     hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, n, fold);
     return hipGetLastError();

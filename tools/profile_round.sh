@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS=${*:---workload c0}
-BENCH="python3 $ROOT/bench.py --steps 300 --warmup 100 --no-cpu-baseline --async-streams 0 --open-loop-chunk 0 $ARGS"
+BENCH="python3 $ROOT/bench.py --steps 300 --warmup 100 --no-cpu-baseline --async-streams 0 --open-loop-chunk 0 --obs-overlap= $ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
