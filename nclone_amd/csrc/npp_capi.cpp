@@ -79,6 +79,7 @@ struct npp_handle_s {
     int n_cuts = 0;                  // 0 = off
     int cut_pct[3] = {0, 0, 0};      // ascending, from the head (most expensive end) of the order
     int live_parts = 1;              // parts of the last npp_step still to be joined (1 = it was not split)
+    bool phase_dirty = true;         // d_phase does not describe the current order / cuts
     uint8_t *d_phase = nullptr;      // [n] which part stepped the env last
     hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // part 0 = the cheap tail of the order, on the caller's stream
     // the streams behind part_stream[1..] and side[][]: created by calibrate_streams(), which keeps only streams whose kernels were
@@ -985,6 +986,7 @@ int npp_set_obs_overlap_parts(npp_handle h, const int *cuts, int n_cuts) {
         for (int q = 0; q < 2; q++)
             if (!h->side_ev[k][q]) HIP_TRY(h, hipEventCreateWithFlags(&h->side_ev[k][q], hipEventDisableTiming));
     if (n_cuts != h->n_cuts) h->owned_valid = false;
+    h->phase_dirty = true;
     h->n_cuts = n_cuts;
     for (int i = 0; i < n_cuts; i++) h->cut_pct[i] = cuts[i];
     if (n_cuts > 0)
@@ -1037,6 +1039,7 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
         const bool fresh = blocks != h->wg_blocks;
         if (fresh) tune_reset(h);
         if (fresh || h->step_launches % 16 == 0) {
+            h->phase_dirty = true;   // (observation overlap) the parts are pieces of this order
             if (fresh) HIP_TRY(h, hipMemsetAsync(h->d_wg_cost, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
             HIP_TRY(h, launch_cost_order(h->d_wg_cost, h->d_wg_order, blocks, NPP_STEP_FOLD, h->stream));
             HIP_TRY(h, hipMemsetAsync(h->d_wg_cost, 0, (size_t)blocks * sizeof(uint32_t), h->stream));   // costs are maxima over the next 16 launches
@@ -1071,7 +1074,6 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
     }
     int pair = -1;
     a.variant = tune_next(h, &pair);
-    a.phase = h->d_phase;   // (NULL unless npp_set_obs_overlap is on) an unsplit launch is "part 0" everywhere
     if (h->n_cuts > 0 && h->d_phase && pair < 0 && (h->tuned || h->variant_pin >= 0 || h->geo_g != 16 || h->zoo_active)) {
         // observation overlap: the pieces of the heavy-first order as launches of their own, the most expensive first; the
         // observation entry points called next launch one kernel per part.  Only with workgroups of whole reachability groups (16
@@ -1091,12 +1093,16 @@ int npp_step(npp_handle h, const uint8_t *d_actions, int frame_skip, const npp_s
             if (a.variant == 2) a.variant = 0;
             if (!h->owned_valid || h->owned_for != h->stream)   // (first split step after npp_set_stream: one-off, synchronises)
                 if (int rc = calibrate_streams(h, streams_needed(h))) return rc;
+            if (h->phase_dirty) {   // the env -> part map, on the caller's stream ahead of the fork
+                HIP_TRY(h, launch_phase_assign(h->d_wg_order, blocks, epb, h->n, edge, h->n_cuts + 1, h->d_phase, h->stream));
+                h->phase_dirty = false;
+            }
             HIP_TRY(h, hipEventRecord(h->ov_ev[0], h->stream));
             h->live_parts = h->n_cuts + 1;
             for (int i = 0; i <= h->n_cuts; i++) {
                 const int q = h->n_cuts - i;
                 KernelArgs ap = a;
-                ap.wg_first = edge[i]; ap.wg_count = edge[i + 1] - edge[i]; ap.phase_id = q;
+                ap.wg_first = edge[i]; ap.wg_count = edge[i + 1] - edge[i];
                 if (q) HIP_TRY(h, hipStreamWaitEvent(h->part_stream[q], h->ov_ev[0], 0));
                 HIP_TRY(h, launch_step(ap, h->part_stream[q]));
             }

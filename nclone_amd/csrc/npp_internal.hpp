@@ -118,9 +118,10 @@ struct KernelArgs {
     uint32_t *wg_cost;
     int wg_first, wg_count;   // split launch: this launch covers entries [wg_first, wg_first + wg_count) of the order; wg_count == 0 =
                               // the whole grid
-    // observation overlap (npp_set_obs_overlap): the step is launched in two parts -- the workgroups expected to run long on a second
-    // stream -- and every env remembers which part stepped it (`phase`, u8[n]); the observation kernels are then launched once per
-    // part, each instance on its part's stream, skipping the envs of the other part (phase_id < 0 or phase == NULL: no filter)
+    // observation overlap (npp_set_obs_overlap): the step is launched in parts -- the workgroups expected to run long on streams of
+    // their own -- and `phase` (u8[n], written by npp_phase_kernel before the parts are launched) says which part steps an env; the
+    // observation kernels are then launched once per part, each instance on its part's stream, skipping the envs of the other
+    // parts (phase == NULL: no filter).  The step kernel itself does not look at it.
     uint8_t *phase;
     int phase_id;
     int variant;          // build variant of the G = 16 plain step kernels (npp_kernels.hip: VariantK); 0 everywhere else
@@ -185,6 +186,7 @@ hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned 
 hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, const float *src_cache, uint32_t *key, float *cache,
                                 const ReachMissDev &md, hipStream_t s);
 // order <- the indices 0 .. n - 1 sorted by cost, heaviest first (128 logarithmic bins; any costs give a permutation)
+hipError_t launch_phase_assign(const uint32_t *order, int blocks, int epb, int n, const int *edge, int parts, uint8_t *phase, hipStream_t s);
 hipError_t launch_spin(long long ticks, hipStream_t s);   // a bounded idle wavefront (stream calibration)
 hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, int fold, hipStream_t s);
 hipError_t launch_tile_tables(hipStream_t s);   // per-device tile gray tables of the player_frame kernel

@@ -1848,7 +1848,6 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 
     STAMP(7);
     if (writer) {
-        if (a.phase) a.phase[env] = (uint8_t)a.phase_id;   // which part of a split step launch stepped this env
         store_state(a, env, n);
         for (int w = 0; w < nw; w++) a.ent_bits[(size_t)w * a.n + env] = eb.w[w * eb.stride];
     }

@@ -1685,6 +1685,26 @@ hipError_t launch_spin(long long ticks, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Observation overlap: which part of a split step launch steps an env, from the heavy-first workgroup order and the cut positions
+// (order entries [0, e1) -> the last part, [e1, e2) -> the one before, ... the tail -> part 0).  Written BEFORE the parts are launched
+// (whenever the order or the cuts change), never by the step kernels themselves: an observation kernel of one part filters on the
+// bytes of ALL envs while the other parts may still be stepping.
+__global__ __launch_bounds__(256) void npp_phase_kernel(const uint32_t *order, int blocks, int epb, int n, int e1, int e2, int e3, int parts,
+                                                        uint8_t *phase) {
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= blocks) return;
+    const int seg = (pos >= e1 ? 1 : 0) + (pos >= e2 ? 1 : 0) + (pos >= e3 ? 1 : 0);   // cuts that lie at or before this entry
+    const uint8_t q = (uint8_t)(parts - 1 - seg);
+    const int env0 = (int)order[pos] * epb;
+    for (int j = 0; j < epb && env0 + j < n; j++) phase[env0 + j] = q;
+}
+hipError_t launch_phase_assign(const uint32_t *order, int blocks, int epb, int n, const int *edge, int parts, uint8_t *phase, hipStream_t s) {
+    const int big = 0x7fffffff;
+    hipLaunchKernelGGL(npp_phase_kernel, dim3((blocks + 255) / 256), dim3(256), 0, s, order, blocks, epb, n, parts > 1 ? edge[1] : big,
+                       parts > 2 ? edge[2] : big, parts > 3 ? edge[3] : big, parts, phase);
+    return hipGetLastError();
+}
+
 hipError_t launch_cost_order(const uint32_t *cost, uint32_t *order, int n, int fold, hipStream_t s) {
     hipLaunchKernelGGL(npp_gv_order_kernel, dim3(1), dim3(1024), 0, s, cost, order, n, fold);
     return hipGetLastError();
