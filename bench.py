@@ -361,7 +361,7 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
     # observation overlap (include/npp_amd.h npp_set_obs_overlap): the same K steps with the expensive workgroups of the step on a
     # second stream and one observation kernel per part; the outputs are the serial ones (tests/test_gpu_round3.py)
     overlap_rep = None
-    if full_obs and args.obs_overlap:
+    if full_obs and args.obs_overlap:   # (config 3 -- short step, one observation kernel -- loses with it: DESIGN.md 4.9)
         overlap_rep = []
         for spec in [x.strip() for x in args.obs_overlap.split(",") if x.strip()]:
             pct = [int(c) for c in spec.split("+")]   # "40" = one cut, "6+25+50" = three
