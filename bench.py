@@ -281,8 +281,9 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
     if full_obs:
         outputs += ["spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features"]
     b = NppBatch(n, device=ctx["local_rank"], autoreset=True, outputs=outputs)
-    STAGES = (("switch_states", lambda: b.switch_states()), ("player_frame", lambda: b.render_player_frame()),
-              ("global_view", lambda: b.render_global_view()), ("reachability", lambda: b.reachability())) if full_obs else ()
+    # (switch_states comes out of the reachability launch: npp_reachability_ex)
+    STAGES = (("player_frame", lambda: b.render_player_frame()), ("global_view", lambda: b.render_global_view()),
+              ("reachability", lambda: b.reachability(with_switch_states=True))) if full_obs else ()
     b.load_levels(levels)
     if args.step_variant >= 0:
         b.set_step_variant(args.step_variant)
@@ -522,7 +523,8 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
         ok = {k: percentiles(v) for k, v in stage_us.items()}
         blk["obs_kernels"] = dict(ok)
         blk["obs_kernels"]["note"] = ("HIP-event time of each observation kernel per step on the launch stream; npp_step includes "
-                                      "spatial_context; reachability = table look-ups for the envs whose (cell, switch) key changed")
+                                      "spatial_context; reachability = table look-ups for the envs whose (cell, switch) key changed, "
+                                      "and switch_states from the same launch (npp_reachability_ex)")
         blk["roofline_render"] = hbm_roofline("npp_render_kernel", ALGO_BYTES_PER_FRAME, n, ok["player_frame"], committed_traffic("player_frame", workload) or (None, None),
                                               "player_frame; raster parity unpinned (no cairo/cv2 reference frame)")
         blk["roofline_global_view"] = hbm_roofline("npp_global_view_kernel", ALGO_BYTES_PER_GLOBAL_VIEW, n, ok["global_view"], committed_traffic("global_view", workload) or (None, None),

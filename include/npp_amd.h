@@ -194,6 +194,9 @@ int npp_switch_states(npp_handle h, float *d_out);
  * mine_sdf_features: the VALUES are the reference's (MineSignedDistanceField); WHEN the reference's observation holds them (its
  * reward calculator builds / clears that SDF) is not modelled -- parity of that life cycle is unpinned. */
 int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status);
+/* ... and, when d_switch_states (f32[n_envs][25]) is not NULL, npp_switch_states's output from the same launch (an idle lane of
+ * every env's lane group writes it: the full observation Dict needs one kernel less). */
+int npp_reachability_ex(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status, float *d_switch_states);
 
 /* The whole gray frame of envs [env0, env0 + count): what NPlayHeadless.render() returns in grayscale mode
  * (nplay_headless.py:144-156, nsim_renderer.py:71-134).  d_out: u8[count][600][1056]. */

@@ -28,7 +28,7 @@ EXPORTS = [
     "npp_render_player_frame", "npp_dump_state", "npp_dump_entities", "npp_dump_level_segments",
     "npp_compile_level_segments", "npp_compile_level_entities", "npp_set_step_variant", "npp_get_step_variant", "npp_num_envs", "npp_num_levels",
     "npp_set_launch_geometry", "npp_get_launch_geometry", "npp_snapshot", "npp_restore", "npp_entity_checksum", "npp_compile_level_zoo", "npp_render_global_view", "npp_switch_states", "npp_set_entity_pos", "npp_step_many", "npp_render_frame", "npp_plan_zoo_block", "npp_reset_ex",
-    "npp_reachability", "npp_reach_compile", "npp_reach_features_host", "npp_reach_compile_miss", "npp_reach_rollout_host", "npp_set_dynamic_truncation", "npp_level_truncation_limit",
+    "npp_reachability", "npp_reachability_ex", "npp_reach_compile", "npp_reach_features_host", "npp_reach_compile_miss", "npp_reach_rollout_host", "npp_set_dynamic_truncation", "npp_level_truncation_limit",
     "npp_set_obs_overlap", "npp_set_obs_overlap_parts", "npp_join",
 ]
 
@@ -109,6 +109,7 @@ def lib():
     L.npp_render_frame.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
     L.npp_plan_zoo_block.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.npp_reachability.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.npp_reachability_ex.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.npp_reach_compile.argtypes = [C.POINTER(C.c_double), C.c_int64] + [C.c_void_p] * 12
     L.npp_reach_features_host.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p]

@@ -1219,6 +1219,10 @@ int npp_switch_states(npp_handle h, float *d_out) {
 }
 
 int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status) {
+    return npp_reachability_ex(h, d_features, d_mine_sdf, d_status, nullptr);
+}
+
+int npp_reachability_ex(npp_handle h, float *d_features, float *d_mine_sdf, int32_t *d_status, float *d_switch_states) {
     if (!h || (!d_features && !d_mine_sdf)) return fail(h, NPP_ERR_INVALID, "npp_reachability: bad arguments");
     if (h->levels.empty()) return fail(h, NPP_ERR_STATE, "npp_reachability: no levels loaded");
     if (h->n_ovr) return fail(h, NPP_ERR_UNSUPPORTED, "npp_reachability: exit switch / door repositioned with npp_set_entity_pos");
@@ -1227,7 +1231,7 @@ int npp_reachability(npp_handle h, float *d_features, float *d_mine_sdf, int32_t
     if (int rc = ensure_reach(h)) return rc;
     KernelArgs a = base_args(h);
     return obs_launch(h, a, 2, tables, [&](const KernelArgs &ka, hipStream_t st) {   // (tables: ensure_reach has just built them)
-        return launch_reach(ka, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, st);
+        return launch_reach(ka, h->d_rhdr, h->d_rblob, h->d_rkey, h->d_rcache, h->rmiss, d_features, d_mine_sdf, d_status, d_switch_states, st);
     });
 }
 

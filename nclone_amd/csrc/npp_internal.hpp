@@ -181,7 +181,7 @@ struct ReachMissDev {
     uint32_t *last_episode;   // [n] episode counter (state word E bits 19-31) seen at the last call
 };
 hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key, float *cache,
-                        const ReachMissDev &md, float *out, float *sdf_out, int32_t *status, hipStream_t s);
+                        const ReachMissDev &md, float *out, float *sdf_out, int32_t *status, float *sw_out, hipStream_t s);
 // envs selected by a.reset_mask (NULL = all): key / cache <- the snapshot's, or "no cached vector" when src_key == NULL
 hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, const float *src_cache, uint32_t *key, float *cache,
                                 const ReachMissDev &md, hipStream_t s);

@@ -21,7 +21,8 @@ namespace {
 constexpr int REACH_EPB = 16;
 
 __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key,
-                                                       float *cache, ReachMissDev md, float *out, float *sdf_out, int32_t *status) {
+                                                       float *cache, ReachMissDev md, float *out, float *sdf_out, int32_t *status,
+                                                       float *sw_out) {
     __shared__ float rows[REACH_EPB * (REACH_DIM + 1)];
     __shared__ float sdfs[REACH_EPB * 3];
     __shared__ int fresh[REACH_EPB];      // 1: the env's row in `rows` was recomputed (write it back to the cache)
@@ -36,6 +37,25 @@ __global__ __launch_bounds__(64) void npp_reach_kernel(KernelArgs a, const Reach
     for (int i = l; i < n_here * ROW; i += 64) rows[i] = cache[(size_t)env0 * ROW + i];
     if (l < REACH_EPB) fresh[l] = 0;
     __syncthreads();
+    // switch_states (npp_switch_states_kernel's arithmetic, npp_render.hip) by the env's second lane, which has nothing else to do:
+    // npp_reachability_ex saves the launch of that 8-us kernel
+    if (sw_out && (l & 3) == 1 && el < n_here) {
+        const LevelHdr &L = a.hdr[a.env_level[env]];
+        const double *ex = reinterpret_cast<const double *>(a.blob + L.off_ent_x);
+        const double *ey = reinterpret_cast<const double *>(a.blob + L.off_ent_y);
+        float *o = sw_out + (size_t)env * 25;
+        for (int k = 0; k < 5; k++) {
+            const int slot = L.locked_slots[k];
+            float v0 = 0.f, v1 = 0.f, v4 = 0.f;
+            if (slot >= 0) {
+                const double sx = ex[slot] / 1056.0, sy = ey[slot] / 600.0;
+                v0 = (float)(sx < 0.0 ? 0.0 : (sx > 1.0 ? 1.0 : sx)); v1 = (float)(sy < 0.0 ? 0.0 : (sy > 1.0 ? 1.0 : sy));
+                const uint32_t st = (a.ent_bits[(size_t)(slot >> 4) * a.n + env] >> ((slot & 15) * 2)) & 3u;
+                v4 = (st & 1u) ? 0.f : 1.f;
+            }
+            o[5 * k] = v0; o[5 * k + 1] = v1; o[5 * k + 2] = v0; o[5 * k + 3] = v1; o[5 * k + 4] = v4;
+        }
+    }
     if ((l & 3) == 0 && el < n_here) {
         const int lvl = a.env_level[env];
         const LevelHdr &L = a.hdr[lvl];
@@ -131,8 +151,9 @@ hipError_t launch_reach_restore(const KernelArgs &a, const uint32_t *src_key, co
 }
 
 hipError_t launch_reach(const KernelArgs &a, const ReachHdr *rh, const unsigned char *rblob, uint32_t *key, float *cache,
-                        const ReachMissDev &md, float *out, float *sdf_out, int32_t *status, hipStream_t s) {
-    hipLaunchKernelGGL(npp_reach_kernel, dim3((a.n + REACH_EPB - 1) / REACH_EPB), dim3(64), 0, s, a, rh, rblob, key, cache, md, out, sdf_out, status);
+                        const ReachMissDev &md, float *out, float *sdf_out, int32_t *status, float *sw_out, hipStream_t s) {
+    hipLaunchKernelGGL(npp_reach_kernel, dim3((a.n + REACH_EPB - 1) / REACH_EPB), dim3(64), 0, s, a, rh, rblob, key, cache, md, out, sdf_out, status,
+                       sw_out);
     return hipGetLastError();
 }
 

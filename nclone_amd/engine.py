@@ -340,15 +340,17 @@ class NppBatch:
         nat.check(self.h, self.lib.npp_switch_states(self.h, C.c_void_p(out.data_ptr())))
         return out
 
-    def reachability(self):
+    def reachability(self, with_switch_states=False):
         """Fill the block's reachability_features [N, 38] / mine_sdf_features [N, 3] / reach_status [N] (whichever are
         enabled) from the current state.  Call once per observation: the 38 floats follow the reference's cache rule
-        (recomputed when the ninja's 24-px cell or exit_switch_activated changed since the previous call)."""
+        (recomputed when the ninja's 24-px cell or exit_switch_activated changed since the previous call).
+        with_switch_states: also fill the block's switch_states from the same launch (instead of a switch_states() call)."""
         t = self.out.t
         ptr = [C.c_void_p(t[k].data_ptr()) if k in t else None for k in ("reachability_features", "mine_sdf_features", "reach_status")]
         if ptr[0] is None and ptr[1] is None:
             raise RuntimeError('enable_outputs("reachability_features") and / or "mine_sdf_features" first')
-        nat.check(self.h, self.lib.npp_reachability(self.h, *ptr))
+        sw = C.c_void_p(t["switch_states"].data_ptr()) if with_switch_states else None
+        nat.check(self.h, self.lib.npp_reachability_ex(self.h, *ptr, sw))
 
     def render_frame(self, env0=0, count=1):
         """uint8 CUDA tensor [count, 600, 1056, 1]: the whole gray frame (the reference's render() array) of some envs."""

@@ -100,13 +100,14 @@ class NppVecEnvironment:
     def _produce(self):
         """Launch the secondary observation kernels (frames, switch_states) on the handle's stream."""
         b = self._b
-        if "switch_states" in b.out.t:
+        fused = "switch_states" in b.out.t and "reachability_features" in b.out.t   # one launch writes both
+        if "switch_states" in b.out.t and not fused:
             b.switch_states()
         if "player_frame" in b.out.t:
             b.render_player_frame()
             b.render_global_view()
         if "reachability_features" in b.out.t:
-            b.reachability()
+            b.reachability(with_switch_states=fused)
         b.join()   # (obs_overlap) the handle's stream waits for the kernels that went to the second stream
 
     def _obs(self, src):

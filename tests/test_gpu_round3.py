@@ -389,3 +389,30 @@ def test_observation_overlap_produces_the_serial_bits(cuts):
         assert a.keys() == c.keys()
         for k in a:
             assert np.array_equal(a[k], c[k], equal_nan=True), k
+
+
+def test_reachability_ex_writes_the_switch_states_of_the_separate_kernel():
+    """npp_reachability_ex: switch_states from the reachability launch = npp_switch_states's output, and the other outputs are
+    those of npp_reachability (door levels, locked doors collected along the way)."""
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import door_levels
+
+    levels, _tags = door_levels()
+    n = 1024
+    outs = ("switch_states", "reachability_features", "mine_sdf_features", "reach_status")
+    acts = torch.from_numpy(np.random.default_rng(9).integers(0, 6, size=(120, n)).astype(np.uint8)).cuda()
+    a, b = (NppBatch(n, autoreset=True, outputs=outs) for _ in range(2))
+    for x in (a, b):
+        x.load_levels(levels)
+        x.assign_levels((np.arange(n) // 16) % len(levels))
+        x.reset()
+    seen_collected = False
+    for t in range(120):
+        a.step(acts[t]); a.switch_states(); a.reachability()
+        b.step(acts[t]); b.reachability(with_switch_states=True)
+        if t % 8 == 7:
+            ha, hb = a.to_host(), b.to_host()
+            for k in outs:
+                assert np.array_equal(ha[k], hb[k]), (t, k)
+            seen_collected = seen_collected or bool((ha["switch_states"].reshape(n, 5, 5)[:, :, 4] == 0).any() and (ha["switch_states"] != 0).any())
+    assert (ha["switch_states"] != 0).any()
