@@ -63,7 +63,7 @@ def _follow_rollouts(levels, names, ra, rp, rf, rm=None):
     b.close()
 
 
-@pytest.mark.parametrize("fixture", ["reach.npz", "reach2.npz"])
+@pytest.mark.parametrize("fixture", ["reach.npz", "reach2.npz", "reach3.npz"])
 def test_reachability_along_reference_rollouts(fixture):
     """reach.npz: 43 levels (locked doors, mines, exit-only); reach2.npz: 83 more (all 26 entity-zoo maps -- drones, thwumps,
     doors of every kind, launch pads ... --, 48 of config 4's generated levels).  7 of the 126 are the levels npp_reachability
@@ -71,10 +71,13 @@ def test_reachability_along_reference_rollouts(fixture):
     a per-episode dictionary, so these rows also pin the episode bookkeeping on the device (state word E's episode counter)."""
     z, names, _sup = _load(fixture)
     ks = list(range(len(names)))
-    assert sum(names[k] in MISS_BRANCH for k in ks) in (2, 5)
     recomputed = int(sum(z["rc%d" % k].sum() for k in ks))
     episodes = int(sum(z["rt%d" % k].sum() for k in ks))
-    assert recomputed > 1800 and episodes > 40 and len(ks) >= 43
+    if fixture == "reach3.npz":   # four of the reference's five official tutorial levels (the fifth: test_reach_host.py)
+        assert len(ks) == 4 and recomputed > 250
+    else:
+        assert sum(names[k] in MISS_BRANCH for k in ks) in (2, 5)
+        assert recomputed > 1800 and episodes > 40 and len(ks) >= 43
     _follow_rollouts([z["m%d" % k] for k in ks], [names[k] for k in ks], np.stack([z["ra%d" % k] for k in ks]),
                      np.stack([z["rp%d" % k] for k in ks]), np.stack([z["rf%d" % k] for k in ks]), np.stack([z["rm%d" % k] for k in ks]))
 

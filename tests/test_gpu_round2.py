@@ -261,16 +261,18 @@ def test_device_guard_and_reset_modes():
     b.close()
 
 
-def test_fast_reset_vs_reference_fixtures(golden):
+@pytest.mark.parametrize("fixture", ["fast", "official"])
+def test_fast_reset_vs_reference_fixtures(golden, fixture):
     """Simulator.fast_reset (nsim.py:78-140) on the device against the reference's own runs (tests/golden/fast.npz: 58 rollouts
-    on mine / locked-door / mine-soup levels and on every zoo map, resets forced mid-flight, fast and full resets mixed):
+    on mine / locked-door / mine-soup levels and on every zoo map, resets forced mid-flight, fast and full resets mixed;
+    official.npz: 15 rollouts on the reference's five official tutorial levels, `nclone/maps/test-maps/`):
     every step's final ninja state within the north-star bars (f32 positions within 1e-5, discrete state identical), the
     entity checksum (positions, speeds and state codes of every entity: movers that keep going across a fast reset),
     game_state and action mask."""
     from nclone_amd.engine import NppBatch
 
-    g = golden.z("fast")
-    names = golden.names("fast")
+    g = golden.z(fixture)
+    names = golden.names(fixture)
     n = len(names)
     levels = [g["m%d" % r] for r in range(n)]
     b = NppBatch(n, autoreset=False)

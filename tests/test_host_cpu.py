@@ -229,7 +229,7 @@ def test_dynamic_truncation_limit_matches_reference():
         assert [calculate_truncation_limit(int(a), m) for m in (1, 2, 5, 20)] == [int(x) for x in vm]
     assert 1200 in ref.values() and 10000 in ref.values() and len(set(ref.values())) > 300
     seen = set()
-    for fx in ("reach.npz", "reach2.npz"):
+    for fx in ("reach.npz", "reach2.npz", "reach3.npz"):
         z = np.load(os.path.join(ROOT, "tests", "golden", fx))
         for k, name in enumerate(bytes(z["names"]).decode().split("\n")):
             lim, area = level_truncation_limit(z["m%d" % k])

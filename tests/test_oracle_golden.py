@@ -299,13 +299,15 @@ def test_oracle_c3_mixed_rollouts_and_tables(golden, oracle_mod):
     assert ticks == 2 * 19173
 
 
-def test_oracle_fast_reset_rollouts(golden, oracle_mod):
+@pytest.mark.parametrize("fixture,rollouts,total_ticks", [("fast", 58, 54603), ("official", 15, 19199)])
+def test_oracle_fast_reset_rollouts(golden, oracle_mod, fixture, rollouts, total_ticks):
     """Simulator.fast_reset (nsim.py:78-140) between episodes, mixed with full resets, on mine / locked-door levels and on
-    every zoo map (tests/golden/make_golden_fast.py ran the reference): ninja trajectory, discrete state, entity checksum at
-    every tick and the per-entity states at every step, bit for bit."""
-    g = golden.z("fast")
-    names = golden.names("fast")
-    assert len(names) == 58
+    every zoo map (tests/golden/make_golden_fast.py ran the reference), and on the reference's five official tutorial levels
+    (`nclone/maps/test-maps/`, make_golden_official.py): ninja trajectory, discrete state, entity checksum at every tick and
+    the per-entity states at every step, bit for bit."""
+    g = golden.z(fixture)
+    names = golden.names(fixture)
+    assert len(names) == rollouts
     ticks = 0
     for r in range(len(names)):
         o = oracle_mod.Oracle("pow")
@@ -334,4 +336,4 @@ def test_oracle_fast_reset_rollouts(golden, oracle_mod):
                 assert o.frame == frame
         assert row == len(T)
         ticks += row
-    assert ticks == 54603
+    assert ticks == total_ticks
