@@ -80,7 +80,7 @@ struct npp_handle_s {
     int cut_pct[3] = {0, 0, 0};      // ascending, from the head (most expensive end) of the order
     int live_parts = 1;              // parts of the last npp_step still to be joined (1 = it was not split)
     bool phase_dirty = true;         // d_phase does not describe the current order / cuts
-    uint8_t *d_phase = nullptr;      // [n] which part stepped the env last
+    uint8_t *d_phase = nullptr;      // [n] which part steps the env (npp_phase_kernel, rewritten when the order or the cuts change)
     hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // part 0 = the cheap tail of the order, on the caller's stream
     // the streams behind part_stream[1..] and side[][]: created by calibrate_streams(), which keeps only streams whose kernels were
     // SEEN to run beside the caller's and beside each other (HIP spreads a process's streams over four hardware queues; two streams
