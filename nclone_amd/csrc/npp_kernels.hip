@@ -1883,12 +1883,15 @@ DEV void run(const KernelArgs &a, unsigned char *smem) {
 //   there is one long chain).
 // So: G >= 16 (up to 16 384 envs) is built for 2 wavefronts per SIMD, G <= 8 and the zoo kernels keep the allocator's free hand
 // (1 wavefront per SIMD, AGPRs as spill space).  -DNPP_MIN_WAVES=1 rebuilds the uncapped G >= 16 kernels for A/B runs.
+#ifndef NPP_ZOO_WAVES   // the zoo kernels (21.8 k instructions, 389 registers): 1 = uncapped; -DNPP_ZOO_WAVES=2 is the A/B build
+#define NPP_ZOO_WAVES 1
+#endif
 #ifndef NPP_MIN_WAVES
 #define NPP_MIN_WAVES 2
 #endif
 
 template <int G, bool LDS_LEVEL, bool ZOO, bool MANY, int V>
-__global__ __launch_bounds__(256, ((ZOO || G < 16 || V == 2) ? 1 : NPP_MIN_WAVES)) void npp_step_kernel(KernelArgs a) {
+__global__ __launch_bounds__(256, (ZOO ? NPP_ZOO_WAVES : ((G < 16 || V == 2) ? 1 : NPP_MIN_WAVES))) void npp_step_kernel(KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     run<G, LDS_LEVEL, ZOO, MANY, V>(a, smem);
 }
