@@ -28,7 +28,9 @@ the slowest 5 % of the launches (the env with the most depenetration iterations 
 Without --workload the line carries every BASELINE config that fits the run (round 3):
   N = 1:  value = config 2 (c0) and `other_configs` = {config3 (mines + player_frame every step), config4_shard (c3mixed, one GPU's
           8192 of the 65 536 envs), config5_full_obs (doors, every Dict observation every step)}, --other-steps (200) timed steps
-          each after their own pre-roll, each with its own roofline block(s);
+          each after their own pre-roll, each with its own roofline block(s); config5_full_obs is timed twice -- every kernel on one
+          stream (`serial`, the pass the per-kernel times and rooflines come from) and with the observation overlap of
+          include/npp_amd.h npp_set_obs_overlap (`obs_overlap`, --obs-overlap: same work, same bits) -- `value` is the better one;
   N > 1:  value = config 2 on N GPUs (so that N = 1 agrees with the line above) and `config4` = c3mixed on the N GPUs with and
           without the RCCL all_gather of the packed observation block.
 With --workload X the line is that workload alone, as before.
