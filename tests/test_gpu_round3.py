@@ -417,3 +417,29 @@ def test_reachability_ex_writes_the_switch_states_of_the_separate_kernel():
                 assert np.array_equal(ha[k], hb[k]), (t, k)
             seen_collected = seen_collected or bool((ha["switch_states"].reshape(n, 5, 5)[:, :, 4] == 0).any() and (ha["switch_states"] != 0).any())
     assert (ha["switch_states"] != 0).any()
+
+
+def test_vec_env_with_observation_overlap_returns_the_same_dict():
+    """NppVecEnvironment(obs_overlap=...) -- split step, one observation kernel per part, switch_states out of the reachability
+    launch, join before the Dict is handed out -- returns the observations, rewards and flags of the plain env, step after step."""
+    from nclone_amd.levels import door_levels
+    from nclone_amd.vec_env import NppVecEnvironment
+
+    levels, _tags = door_levels()
+    n = 1024
+    kw = dict(enable_visual_observations=True, enable_spatial_context=True, enable_switch_states=True, enable_reachability=True,
+              output="numpy", truncation_limit=60)
+    a = NppVecEnvironment(levels, n, **kw)
+    b = NppVecEnvironment(levels, n, obs_overlap=45, **kw)
+    b.batch.set_step_variant(0)   # pinned: the split starts with the first step
+    a.batch.set_step_variant(0)
+    oa, _ = a.reset(seed=1)
+    ob, _ = b.reset(seed=1)
+    acts = np.random.default_rng(2).integers(0, 6, size=(50, n))
+    for t in range(50):
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        for k in ra[0]:
+            assert np.array_equal(ra[0][k], rb[0][k], equal_nan=True), (t, k)
+        assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]) and np.array_equal(ra[3], rb[3]), t
+    assert set(ra[0]) >= {"player_frame", "global_view", "switch_states", "reachability_features", "spatial_context"}
+    a.close(); b.close()
