@@ -10,11 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 
 from nclone_amd.engine import NppBatch
-from nclone_amd.levels import door_levels
+from nclone_amd import levels as level_sets
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 n = 4096
-levels, _ = door_levels()
+wl = sys.argv[2] if len(sys.argv) > 2 else "doors"
+levels, _ = {"doors": level_sets.door_levels, "zoo": level_sets.zoo_levels, "mines": level_sets.mine_levels}[wl]()
 outs = ("positions", "spatial_context", "switch_states", "player_frame", "global_view", "reachability_features", "mine_sdf_features", "reach_status")
 acts = torch.from_numpy(np.random.default_rng(3).integers(0, 6, size=(steps, n)).astype(np.uint8)).cuda()
 digests = []
@@ -38,7 +39,7 @@ for cuts in (0, 50, (10, 30, 60)):
     f, di = b.dump_state()
     hs = torch.stack(hs).cpu().numpy()
     digests.append((hs, hashlib.sha256(f.tobytes() + di.tobytes()).hexdigest()))
-    print("cuts", cuts, "steps", steps, "state", digests[-1][1][:16], flush=True)
+    print(wl, "cuts", cuts, "steps", steps, "state", digests[-1][1][:16], flush=True)
     del b
 for hs, st in digests[1:]:
     bad = np.flatnonzero(hs != digests[0][0])
