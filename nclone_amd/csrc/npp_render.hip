@@ -991,7 +991,8 @@ __device__ inline void gv_cell(const GvLds &L, int nd, int nb, const uint8_t *ca
     const float tx_wh = tx.wh, tx_wm = tx.wm, tx_wt = tx.wt, ty_wh = ty.wh, ty_wm = ty.wm, ty_wt = ty.wt;
     const int y = ty.a + sub;   // this lane's source row (a destination row spans at most 6)
     // issued before the mask work so that their latency is hidden: the row's static hs and its static picture slice
-    // (at most 12 pixels -> four aligned dwords; the table is padded by 16 bytes)
+    // (at most 12 pixels -> four aligned dwords; the table is padded by 16 bytes).  (Issuing them a whole cell ahead from the caller's
+    // loop was measured: 133 -> 137 us, the extra live registers cost more than the latency.)
     const int xb0 = tx.a & ~3;
     const int yl = y < 599 ? y : 599;
     const float hs_static = hrow[(size_t)yl * GV_COLS + c];
@@ -1040,19 +1041,31 @@ __device__ inline void gv_cell(const GvLds &L, int nd, int nb, const uint8_t *ca
     int pn = 0, pi0 = 0, pi1 = 0, pi2 = 0, pi3 = 0;
     bool inline_compose = false;
     if (row_live) {
-        for (int b = 0; b < nb; b++) {
-            const short4 bx = L.box[b];
-            if (bx.z >= tx.a && bx.x < tx.b && bx.w >= y && bx.y <= y) {
-                hx0 = hx0 < bx.x ? hx0 : bx.x; hx1 = hx1 > bx.z ? hx1 : bx.z;
-                if (b < GV_PBOX && L.prect[b].z > 0) {
-                    if (pn == 0) pi0 = b;
-                    else if (pn == 1) pi1 = b;
-                    else if (pn == 2) pi2 = b;
-                    else if (pn == 3) pi3 = b;
-                    else inline_compose = true;
-                    pn += 1;
-                } else {
-                    inline_compose = true;
+        // four boxes per trip: their LDS reads (box, patch rectangle) are issued together instead of one dependent pair per box
+        for (int b0 = 0; b0 < nb; b0 += 4) {
+            short4 bxs[4], prs[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int b = b0 + u < nb ? b0 + u : nb - 1;
+                bxs[u] = L.box[b];
+                prs[u] = L.prect[b < GV_PBOX ? b : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int b = b0 + u;
+                const short4 bx = bxs[u];
+                if (b < nb && bx.z >= tx.a && bx.x < tx.b && bx.w >= y && bx.y <= y) {
+                    hx0 = hx0 < bx.x ? hx0 : bx.x; hx1 = hx1 > bx.z ? hx1 : bx.z;
+                    if (b < GV_PBOX && prs[u].z > 0) {
+                        if (pn == 0) pi0 = b;
+                        else if (pn == 1) pi1 = b;
+                        else if (pn == 2) pi2 = b;
+                        else if (pn == 3) pi3 = b;
+                        else inline_compose = true;
+                        pn += 1;
+                    } else {
+                        inline_compose = true;
+                    }
                 }
             }
         }
@@ -1072,6 +1085,29 @@ __device__ inline void gv_cell(const GvLds &L, int nd, int nb, const uint8_t *ca
             GV_ROW_RECT(0, rx0, rw0, ro0) GV_ROW_RECT(1, rx1, rw1, ro1) GV_ROW_RECT(2, rx2, rw2, ro2) GV_ROW_RECT(3, rx3, rw3, ro3)
 #undef GV_ROW_RECT
             if (!inline_compose) {
+#ifndef NPP_GV_NO_UNROLL_X
+                // a slice is 11 or 12 pixels: a fixed trip count lets the patch reads of all of them be in flight together (the sum
+                // stays in x order)
+                int pixv[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const int x = tx.a + i;
+                    const int o = x - xb0, sh = (o & 3) * 8;
+                    int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
+                    int pa = -1;
+                    if (x >= rx0 && x < rx0 + rw0) pa = ro0 + x;
+                    else if (x >= rx1 && x < rx1 + rw1) pa = ro1 + x;
+                    else if (x >= rx2 && x < rx2 + rw2) pa = ro2 + x;
+                    else if (x >= rx3 && x < rx3 + rw3) pa = ro3 + x;
+                    const int pv = L.patch[pa < 0 ? 0 : pa];
+                    pixv[i] = pa < 0 ? pix : pv;
+                }
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const int x = tx.a + i;
+                    if (x < tx.b) hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pixv[i];
+                }
+#else
                 for (int x = tx.a; x < tx.b; x++) {
                     const int o = x - xb0, sh = (o & 3) * 8;
                     int pix = (int)(((o < 4 ? pw.x : (o < 8 ? pw.y : (o < 12 ? pw.z : pw.w))) >> sh) & 0xffu);
@@ -1082,6 +1118,7 @@ __device__ inline void gv_cell(const GvLds &L, int nd, int nb, const uint8_t *ca
                     else if (x >= rx3 && x < rx3 + rw3) pix = L.patch[ro3 + x];
                     hs += tab_w3(x, tx_s1, tx_s2, tx_wh, tx_wm, tx_wt) * (float)pix;
                 }
+#endif
             } else {
                 const uint32_t *cp = reinterpret_cast<const uint32_t *>(canvas + (size_t)y * 1056 + xb0);
                 const uint4 cw = make_uint4(cp[0], cp[1], cp[2], cp[3]);
@@ -1157,6 +1194,21 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
     const int lvl = __builtin_amdgcn_readfirstlane(a.env_level[env]);
     const LevelHdr &H = a.hdr[lvl];
     const double px = a.f64[(size_t)F_X * a.n + env], py = a.f64[(size_t)F_Y * a.n + env];
+    // issued here, consumed by the draw-list walk after the copy of the view: the first 128 draw records (one per lane and pass) and
+    // the env's entity state words next to the level's init words, one word per lane (the walk then reads a record's two state codes
+    // with a cross-lane read instead of two dependent global loads)
+    const uint4 *recs = reinterpret_cast<const uint4 *>(a.blob + H.off_draw_recs);
+    const uint32_t *init_words = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
+    const uint32_t n_draw = H.n_ent + H.n_mov;
+    const bool words_in_lanes = H.n_words <= 64u;
+    uint4 rc_pre0 = make_uint4(0u, 0u, 0u, 0u), rc_pre1 = rc_pre0;
+    if ((uint32_t)lane < n_draw) rc_pre0 = recs[lane];
+    if ((uint32_t)lane + 64u < n_draw) rc_pre1 = recs[lane + 64];
+    uint32_t w_now = 0u, w_init = 0u;
+    if (words_in_lanes && (uint32_t)lane < H.n_words) {
+        w_now = a.ent_bits[(size_t)lane * a.n + env];
+        w_init = init_words[lane];
+    }
     for (int i = lane; i < GV_WORDS; i += 64) L.dirty[i] = 0u;
     if (lane == 0) { L.ctr[0] = 0; L.ctr[1] = 0; L.ctr[2] = 0; }
     {   // the level's view, to be patched below
@@ -1224,17 +1276,22 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
         }
     }
     {
-        const uint4 *recs = reinterpret_cast<const uint4 *>(a.blob + H.off_draw_recs);
-        const uint32_t *init_words = reinterpret_cast<const uint32_t *>(a.blob + H.off_init_words);
-        const uint32_t n_draw = H.n_ent + H.n_mov;
         const double *zhead = a.zoo ? a.zoo + (size_t)env * a.zoo_words : nullptr;
         const uint32_t ovr = zhead ? reinterpret_cast<const uint32_t *>(zhead + 3)[0] : 0u;   // npp_set_entity_pos
         for (uint32_t k0 = 0; k0 < n_draw; k0 += 64) {
             const uint32_t k = k0 + lane;
             bool kc = false, ki = false;
             Draw d = {}, di = {};
+            uint4 rc = k0 == 0 ? rc_pre0 : rc_pre1;
+            if (k0 >= 128 && k < n_draw) rc = recs[k];
+            // both state codes of the record's slot through cross-lane reads of the word lanes (every lane takes part)
+            uint32_t sh_now = 0u, sh_init = 0u;
+            if (words_in_lanes) {
+                const int wl = (k < n_draw && !(rc.z & 0x8000u)) ? (int)((rc.z >> 16) >> 4) : 0;
+                sh_now = (uint32_t)__shfl((int)w_now, wl, 64);
+                sh_init = (uint32_t)__shfl((int)w_init, wl, 64);
+            }
             if (k < n_draw) {
-                const uint4 rc = recs[k];
                 const float x0 = __uint_as_float(rc.x), y0 = __uint_as_float(rc.y);
                 float x = x0, y = y0;
                 const uint32_t info = rc.z;
@@ -1251,8 +1308,9 @@ __global__ __launch_bounds__(64 * GV_WPB, NPP_GV_WAVES) void npp_global_view_ker
                     if (slot == H.obs_switch && (ovr & ZOO_OVR_SWITCH)) { x = (float)zhead[4]; y = (float)zhead[5]; }
                     if (slot == H.obs_door && (ovr & ZOO_OVR_DOOR)) { x = (float)zhead[6]; y = (float)zhead[7]; }
                 }
-                const uint32_t st_now = mover ? 1u : ent_state_of(a, env, slot);
-                const uint32_t st_init = (init_words[slot >> 4] >> ((slot & 15) * 2)) & 3u;
+                const uint32_t st_now = mover ? 1u : (words_in_lanes ? (sh_now >> ((slot & 15) * 2)) & 3u : ent_state_of(a, env, slot));
+                const uint32_t st_init = words_in_lanes && !mover ? (sh_init >> ((slot & 15) * 2)) & 3u
+                                                                  : (init_words[slot >> 4] >> ((slot & 15) * 2)) & 3u;
                 if (live && !(x < wx0 || x > wx1 || y < wy0 || y > wy1)) kc = rec_drawable(info, x, y, st_now, d);
                 // the usual record: a static entity in the state and at the place it has after a reset -> the drawable IS the
                 // init drawable, no dirty box, one evaluation instead of two (most of a level's mines, all its untouched gold)
