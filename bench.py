@@ -66,7 +66,7 @@ ALGO_BYTES_PER_REACH = 340
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def committed_traffic(kernel="step", workload="c0"):
+def committed_traffic(kernel="step", workload="c0", variant=None):
     """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs) of this same
     command; tools/profile_round.sh collects them and tools/summarize_profiles.py writes profiles/<round>_summary.json (the
     headline workload), <round>_render_summary.json (config 3: mines + player_frame) and <round>_c5_summary.json (config 5: doors,
@@ -85,6 +85,10 @@ def committed_traffic(kernel="step", workload="c0"):
         try:
             j = json.load(open(f))
             t = j.get("by_kernel", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+            if kernel == "step" and variant is not None:   # the row of the build variant this run launched (the profile holds all three)
+                tv = j.get("by_kernel", {}).get("step", {}).get("variants", {}).get(str(int(variant)), {}).get("hbm_bytes_per_launch")
+                if tv:
+                    t, name = tv, name + " (step build variant %d)" % int(variant)
             if t is None and kernel == "step":
                 t = j.get("traffic", {}).get("hbm_bytes_per_launch")          # round 1-2 files
             if t is None and kernel == "player_frame":
@@ -512,7 +516,8 @@ def run_workload(ctx, workload, K, W, P, player_frame=False, full_obs=False, gat
                    "ticks_per_s": value * FRAME_SKIP, "preroll_steps": P, "player_frame": bool(player_frame or full_obs),
                    "gather_obs": bool(gather_rep is not None), "terminated_frac_last_step": done_frac},
         "launch_us": pl, "step_variant": step_variant, "stragglers": stragglers,
-        "roofline": hbm_roofline("npp_step_kernel", ALGO_BYTES_PER_ENV_STEP, n, pl, committed_traffic("step", workload) or (None, None), STEP_NOTE),
+        "roofline": hbm_roofline("npp_step_kernel", ALGO_BYTES_PER_ENV_STEP, n, pl,
+                                 committed_traffic("step", workload, step_variant["variant"]) or (None, None), STEP_NOTE),
     }
     if full_obs:
         blk["config"]["full_obs"] = True

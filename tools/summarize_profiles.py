@@ -144,6 +144,34 @@ def main():
                 e.update({"read_bytes_per_launch_raw": fs * 1024, "read_bytes_per_launch_x2": fs * 2048, "write_bytes_per_launch": ws * 1024,
                           "hbm_bytes_per_launch": fs * 2048 + ws * 1024})
             by_kernel[key] = e
+        # the step kernel's build variants (npp_set_step_variant) apart: the pre-roll's autotuner windows run all three, and the variant of
+        # the timed region can differ between the trace pass and a PMC pass -- bench.py picks the row of the variant IT ran
+        import re
+        variants = {}
+        for name in ("fetch", "write"):
+            cc = find(os.path.join(src, name), "*counter_collection.csv")
+            if not cc:
+                continue
+            acc = collections.defaultdict(lambda: collections.defaultdict(float))
+            for r in csv.DictReader(open(cc)):
+                mt = re.search(r"npp_step_kernel<16, (true|false), false, false, (\d)>", r["Kernel_Name"])
+                if mt and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    acc[mt.group(2)][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+            for v, d in acc.items():
+                ids = sorted(d)[-TIMED:]
+                variants.setdefault(v, {})["FETCH_SIZE" if name == "fetch" else "WRITE_SIZE"] = (sum(d[i] for i in ids) / len(ids), len(ids))
+        sv = {}
+        for v, t in variants.items():
+            if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+                fs, ws = t["FETCH_SIZE"][0], t["WRITE_SIZE"][0]
+                sv[v] = {"dispatches": min(t["FETCH_SIZE"][1], t["WRITE_SIZE"][1]), "read_bytes_per_launch_raw": fs * 1024,
+                         "read_bytes_per_launch_x2": fs * 2048, "write_bytes_per_launch": ws * 1024, "hbm_bytes_per_launch": fs * 2048 + ws * 1024}
+        if sv and "step" in by_kernel:
+            by_kernel["step"]["variants"] = sv
+            mt = re.search(r"false, false, (\d)>", by_kernel["step"]["kernel"])
+            if mt and mt.group(1) in sv:   # the row of the variant the TRACE pass timed (a PMC pass may have settled on another)
+                by_kernel["step"].update({k: v for k, v in sv[mt.group(1)].items() if k != "dispatches"})
+                by_kernel["step"]["traffic_of_variant"] = int(mt.group(1))
     if by_kernel:
         out["by_kernel"] = by_kernel
     sq = find(os.path.join(src, "sq"), "*counter_collection.csv")
