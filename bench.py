@@ -166,7 +166,7 @@ def parse_args(argv=None):
                     help="timed steps of each block of `other_configs` / `config4` (0 = leave them out)")
     ap.add_argument("--step-variant", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="pin a build variant of the step kernel (A/B runs); -1 = the autotuner decides (default)")
-    ap.add_argument("--obs-overlap", type=str, default="40",
+    ap.add_argument("--obs-overlap", type=str, default="50",
                     help="full-obs workloads: comma-separated percentages for npp_set_obs_overlap (the most expensive workgroups of the step "
                          "go to a second stream and the observation kernels of the other envs run beside them; same bits).  Each is timed "
                          "after the serial pass and reported under `obs_overlap`; the block's `value` is the best of them, the serial pass "
