@@ -443,3 +443,31 @@ def test_vec_env_with_observation_overlap_returns_the_same_dict():
         assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]) and np.array_equal(ra[3], rb[3]), t
     assert set(ra[0]) >= {"player_frame", "global_view", "switch_states", "reachability_features", "spatial_context"}
     a.close(); b.close()
+
+
+def test_observation_overlap_argument_checks():
+    """npp_set_obs_overlap_parts refuses cuts that are not ascending percentages in (0, 100) or more than three of them; switching
+    the overlap off and on again keeps working (streams are chosen once per caller stream)."""
+    from nclone_amd import _native as nat
+    from nclone_amd.engine import NppBatch
+    from nclone_amd.levels import door_levels
+
+    levels, _ = door_levels()
+    b = NppBatch(256, autoreset=True, outputs=("player_frame",))
+    b.load_levels(levels[:4])
+    b.assign_levels((np.arange(256) // 64) % 4)
+    lib = nat.lib()
+    for bad in ([0], [100], [50, 40], [10, 10], [10, 20, 30, 40]):
+        arr = (C.c_int * len(bad))(*bad)
+        assert lib.npp_set_obs_overlap_parts(b.h, arr, len(bad)) == 1, bad          # NPP_ERR_INVALID
+    assert lib.npp_set_obs_overlap(b.h, 100) == 1 and lib.npp_set_obs_overlap(b.h, -1) == 1
+    acts = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    b.set_step_variant(1)
+    for cuts in (30, 0, (20, 60), 0, 50):
+        b.set_obs_overlap(cuts)
+        for _ in range(3):
+            b.step(acts)
+            b.render_player_frame()
+        b.join()
+    b.sync()
+    b.close()
