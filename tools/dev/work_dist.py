@@ -31,5 +31,9 @@ for thr in (16, 32, 64, 128, 256):
     print("%s: iterations >= %3d: envs %.4f  wavefronts(4) %.4f  workgroups(16) %.4f" % (wl, thr, e, wv, wg))
 print("mean iterations: env %.2f, wavefront max %.2f, workgroup max %.2f" % (w.mean(), w.reshape(100, n // 4, 4).max(axis=2).mean(), w.reshape(100, n // 16, 16).max(axis=2).mean()))
 # persistence: does an env heavy at step t stay heavy at t + 16?
-h0, h1 = w[:-16] >= 64, w[16:] >= 64
-print("P(heavy at t+16 | heavy at t) = %.3f, P(heavy) = %.4f" % ((h0 & h1).sum() / max(1, h0.sum()), h0.mean()))
+for lag in (1, 2, 4, 8, 16):
+    h0, h1 = w[:-lag] >= 64, w[lag:] >= 64
+    g0 = w.reshape(100, n // 16, 16).max(axis=2)
+    k0, k1 = g0[:-lag] >= 64, g0[lag:] >= 64
+    print("lag %2d: P(env heavy again) = %.3f (base %.4f); P(workgroup heavy again) = %.3f (base %.4f)" % (
+        lag, (h0 & h1).sum() / max(1, h0.sum()), h0.mean(), (k0 & k1).sum() / max(1, k0.sum()), k0.mean()))
